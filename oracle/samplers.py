@@ -1,0 +1,218 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the two samplers on the GuideGen
+hot path (CCDM categorical reverse chain; LDM DDIM + autoregressive slice loop).
+
+Every function cites the reference lines it restates.  RNG is always an explicit
+*tape* (pre-drawn tensors), never an implicit global generator, so the same tape
+can be fed to the HIP path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+# ============================================================================= CCDM (A1-A4)
+def ccdm_cosine_schedule(time_steps: int):
+    """cosine_schedule (ccdm/ddpm/models/diffusion_denoising.py:25-39).
+    Quirks kept: `s` is always 0.008; cumalphas is evaluated at t=0..T-1 in fp32
+    tensor math and is NOT cumprod(alphas); betas come from python float64 then
+    torch.tensor -> fp32, capped at 0.999."""
+    s = 0.008
+    t = torch.arange(0, time_steps)
+    cumalphas = torch.cos(((t / time_steps + s) / (1 + s)) * (math.pi / 2)) ** 2
+
+    def f(u):
+        return math.cos((u + s) / (1.0 + s) * math.pi / 2) ** 2
+
+    betas = torch.tensor([min(1 - f((i + 1) / time_steps) / f(i / time_steps), 0.999) for i in range(time_steps)])
+    alphas = 1 - betas
+    return betas, alphas, cumalphas
+
+
+def ccdm_linear_schedule(time_steps: int, start=1e-2, end=0.2):
+    """linear_schedule (diffusion_denoising.py:18-22)."""
+    betas = torch.linspace(start, end, time_steps)
+    alphas = 1 - betas
+    return betas, alphas, torch.cumprod(alphas, dim=0)
+
+
+def ccdm_schedule(name: str, time_steps: int):
+    return {"cosine": ccdm_cosine_schedule, "linear": ccdm_linear_schedule}[name](time_steps)
+
+
+def ccdm_step_scalars(alphas: torch.Tensor, cumalphas: torch.Tensor, t: int):
+    """(a, abar) used by theta_post_prob at (1-based) step t (diffusion_denoising.py:114-122):
+    t0=t-1; a=alphas[t0]; abar=cumalphas[t0-1] (python wrap-around at t0==0, then
+    overwritten): a->0, abar->1 when t0==0."""
+    t0 = t - 1
+    if t0 == 0:
+        return 0.0, 1.0
+    return float(alphas[t0]), float(cumalphas[t0 - 1])
+
+
+def theta_post_prob(xt: torch.Tensor, p0: torch.Tensor, a: float, abar: float) -> torch.Tensor:
+    """DiffusionModel.theta_post_prob (diffusion_denoising.py:105-139), channels on dim 1.
+    out[c] = sum_d  A[c]*B[c,d] / (sum_c' A[c']*B[c',d]) * p0[d]
+    A[c]=a*xt[c]+(1-a)/K ; B[c,d]=abar*delta_cd+(1-abar)/K.
+    Written with an explicit [K,K] broadcast so that the summation order over d
+    matches a plain left-to-right loop (what the C restatement and HIP kernel do)."""
+    K = xt.shape[1]
+    a = torch.tensor(a, dtype=torch.float32)
+    abar = torch.tensor(abar, dtype=torch.float32)
+    A = a * xt + (1 - a) / K                                            # [B,K,...]
+    eye = torch.eye(K, dtype=torch.float32).reshape((1, K, K) + (1,) * (xt.ndim - 2))
+    Bm = abar * eye + (1 - abar) / K                                    # [1,K(c),K(d),...]
+    aux = A[:, :, None] * Bm                                            # [B,c,d,...]
+    post = aux / aux.sum(dim=1, keepdim=True)
+    out = torch.zeros_like(xt)
+    for d in range(K):                                                  # fixed order d=0..K-1
+        out = out + post[:, :, d] * p0[:, d:d + 1]
+    return out
+
+
+def race_sample_labels(probs: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    """OneHotCategoricalBCHW(probs).sample() (one_hot_categorical.py:30-32) ==
+    torch.multinomial(p, 1, True) == argmax_k p_k / E_k  with E ~ Exp(1) drawn
+    as one `exponential_` call of shape [N*spatial, K] in channels-last row order
+    (SURVEY 8a A3).  `probs` is [B,K,spatial...]; `E` is [B*spatial, K].
+    Categorical's constructor renormalises: p / p.sum(-1)."""
+    K = probs.shape[1]
+    p = probs.permute(0, *range(2, probs.ndim), 1).reshape(-1, K)
+    p = p / p.sum(-1, keepdim=True)
+    lab = torch.argmax(p / E, dim=-1)
+    return lab.reshape(probs.shape[0], *probs.shape[2:])
+
+
+def one_hot_bchw(labels: torch.Tensor, K: int, dtype=torch.float32) -> torch.Tensor:
+    oh = torch.nn.functional.one_hot(labels, K)
+    return oh.permute(0, labels.ndim, *range(1, labels.ndim)).to(dtype)
+
+
+def ccdm_t_values(T: int, init_t: Optional[int] = None) -> List[int]:
+    """Step list of forward_denoising (diffusion_denoising.py:176-201), including the
+    `t = 10000+K` sub-sampling convention (:190-197)."""
+    if init_t is None:
+        init_t = T
+    if init_t > 10000:
+        K = init_t % 10000
+        assert 0 < K <= T
+        if K == T:
+            return list(range(K, 0, -1))
+        return [round(v) for v in np.linspace(T, 1, K)]
+    return list(range(init_t, 0, -1))
+
+
+def ccdm_chain(unet_probs: Callable[[torch.Tensor, float], torch.Tensor], x_T_labels: torch.Tensor, K: int,
+               schedule: str, T: int, tapes: Sequence[torch.Tensor], step_T_sample: str = "confidence",
+               init_t: Optional[int] = None, trace: Optional[list] = None):
+    """DenoisingModel.forward_denoising (diffusion_denoising.py:176-227).
+    `unet_probs(xt_onehot, t_float)` returns softmax probs p(x0) [B,K,...].
+    `tapes[i]` is the exponential tape consumed by the i-th sampled step (t>1).
+    Returns labels (argmax) and, for 'confidence', the final probs."""
+    _, alphas, cumalphas = ccdm_schedule(schedule, T)
+    labels = x_T_labels
+    ti = 0
+    probs = None
+    for t in ccdm_t_values(T, init_t):
+        xt = one_hot_bchw(labels, K)
+        p0 = unet_probs(xt, float(t))
+        a, abar = ccdm_step_scalars(alphas, cumalphas, t)
+        probs = theta_post_prob(xt, p0, a, abar)
+        probs = torch.clamp(probs, min=1e-12)
+        if t > 1:
+            labels = race_sample_labels(probs, tapes[ti])
+            ti += 1
+        else:
+            pl = probs.permute(0, *range(2, probs.ndim), 1)
+            pl = pl / pl.sum(-1, keepdim=True)         # Categorical normalisation
+            labels = torch.argmax(pl, dim=-1)
+            probs = pl.permute(0, probs.ndim - 1, *range(1, probs.ndim - 1))
+        if trace is not None:
+            trace.append(dict(t=t, labels=labels.clone(), probs=probs.clone()))
+    return labels, probs
+
+
+# ============================================================================= LDM (B1, B2, B8)
+def ldm_linear_betas(n_timestep=1000, linear_start=1e-4, linear_end=2e-2) -> np.ndarray:
+    """make_beta_schedule('linear') (ldm/modules/diffusionmodules/util.py:21-26): fp64."""
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+
+
+def ldm_alphas_cumprod(betas: np.ndarray) -> np.ndarray:
+    """DDPM.register_schedule (ldm/models/diffusion/ddpm.py:118-140): numpy fp64 cumprod, stored fp32."""
+    return np.cumprod(1.0 - betas, axis=0)
+
+
+def ddim_schedule(alphas_cumprod_f32: torch.Tensor, S: int, eta: float = 0.0, T: int = 1000):
+    """DDIMSampler.make_schedule (ldm/models/diffusion/ddim.py:24-53) with
+    make_ddim_timesteps('uniform') and make_ddim_sampling_parameters (util.py:46-74).
+    Input is the model's fp32 `alphas_cumprod` buffer."""
+    c = T // S
+    ts = np.asarray(list(range(0, T, c))) + 1
+    ac = alphas_cumprod_f32.cpu()
+    alphas = ac[ts]
+    alphas_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    sqrt_1m = np.sqrt(1.0 - alphas)
+    return dict(timesteps=ts, alphas=alphas, alphas_prev=torch.as_tensor(alphas_prev),
+                sigmas=torch.as_tensor(sigmas), sqrt_one_minus_alphas=torch.as_tensor(sqrt_1m))
+
+
+def ddim_step(x, e_t, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise):
+    """p_sample_ddim update (ddim.py:190-204); fp32 scalars as produced by torch.full(...)."""
+    a_t = torch.tensor(float(a_t), dtype=torch.float32)
+    a_prev = torch.tensor(float(a_prev), dtype=torch.float32)
+    sigma_t = torch.tensor(float(sigma_t), dtype=torch.float32)
+    s1m = torch.tensor(float(sqrt_one_minus_at), dtype=torch.float32)
+    pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+    dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
+    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise
+    return x_prev, pred_x0
+
+
+def ddim_sample(eps_model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x_T: torch.Tensor,
+                noises: Sequence[torch.Tensor], alphas_cumprod_f32: torch.Tensor, S: int, eta: float = 0.0,
+                T: int = 1000):
+    """DDIMSampler.ddim_sampling (ddim.py:114-164): time_range = flip(ddim_timesteps);
+    index = total-i-1; one noise tensor consumed per step even at sigma=0 (:201)."""
+    sch = ddim_schedule(alphas_cumprod_f32, S, eta, T)
+    ts = sch["timesteps"]
+    total = ts.shape[0]
+    img = x_T
+    pred_x0 = None
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((img.shape[0],), int(step), dtype=torch.long)
+        e_t = eps_model(img, t)
+        img, pred_x0 = ddim_step(img, e_t, sch["alphas"][index], sch["alphas_prev"][index], sch["sigmas"][index],
+                                 sch["sqrt_one_minus_alphas"][index], noises[i])
+    return img, pred_x0
+
+
+def slice_minmax_normalise(ds: torch.Tensor) -> torch.Tensor:
+    """(ds - ds.min())/(ds.max()-ds.min()) over the WHOLE batch tensor (latentdiffusion/sample_diffusion.py:222)."""
+    return (ds - ds.min()) / (ds.max() - ds.min())
+
+
+def autoregressive_slices(cond_encode, eps_model_for, decode, wholemask: torch.Tensor, n_samples: int, latent_shape,
+                          draw_noise, alphas_cumprod_f32, S: int):
+    """sample_cond slice loop (sample_diffusion.py:196-224).
+    wholemask [1,1,D,H,W] (label/255).  `cond_encode(concat_cond)->c`,
+    `eps_model_for(c)->(x,t)->eps`, `decode(z)->image`, `draw_noise(shape)` supplies
+    x_T then the per-step noises in ddim.py:124,201 order."""
+    nz = torch.where(wholemask.sum((0, 1, 3, 4)))[0]
+    start, end = int(nz[0]), int(nz[-1])
+    samples = torch.zeros((n_samples,) + tuple(wholemask.shape[1:]), dtype=torch.float32)
+    gen_mask = wholemask.repeat(n_samples, 1, 1, 1, 1)
+    for m in range(start - 1, end + 1):
+        concat_cond = torch.cat([samples[:, :, max(0, m - 1)], gen_mask[:, :, m]], dim=1)
+        c = cond_encode(concat_cond)
+        x_T = draw_noise((n_samples,) + tuple(latent_shape))
+        noises = [draw_noise((n_samples,) + tuple(latent_shape)) for _ in range(S)]
+        z, _ = ddim_sample(eps_model_for(c), x_T, noises, alphas_cumprod_f32, S)
+        ds = decode(z)
+        samples[:, :, m] = slice_minmax_normalise(ds)
+    return samples
