@@ -1,0 +1,182 @@
+/* guidegen_hip.h -- C-ABI of libguidegen_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (OvO1111/JointImageGeneration) has no native boundary: every hot-path "kernel" is an
+ * ATen op dispatched from Python.  Each entry point below replaces the ATen call sites
+ * cited beside it; the Python modules in jointimagegeneration_amd/ call these through ctypes exactly
+ * where the reference modules call torch (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions:
+ *   - plain C: device pointers as void*, explicit sizes, no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = default stream);
+ *   - the library never allocates, frees or retains device memory and never synchronises the device:
+ *     every call only enqueues kernels on `stream`, so it is legal inside hipGraph capture;
+ *   - every function returns 0 (GG_OK) or a negative gg_status; gg_last_error() gives a thread-local message;
+ *   - activations are channels-last ("CL"): [N, D, H, W, C] with C contiguous, bf16 unless stated,
+ *     2-D tensors use D == 1; the channel count of a bf16 CL tensor is padded to a multiple of 32
+ *     and the pad lanes hold zeros.
+ */
+#ifndef GUIDEGEN_HIP_H
+#define GUIDEGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GG_OK = 0,
+    GG_ERR_BAD_SHAPE = -1,
+    GG_ERR_BAD_DTYPE = -2,
+    GG_ERR_UNSUPPORTED = -3,
+    GG_ERR_WORKSPACE_TOO_SMALL = -4,
+    GG_ERR_HIP = -5
+} gg_status;
+
+typedef enum { GG_BF16 = 0, GG_F32 = 1 } gg_dtype;
+
+const char *gg_last_error(void);
+int gg_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (v_mfma_f32_16x16x32_bf16), bf16 in / fp32 accumulate.
+ * Replaces nn.Conv{1,2,3}d call sites:
+ *   ResBlock in_layers[2]/out_layers[3]/skip_connection  ccdm/.../unet_openai/unet.py:188-228, ldm/.../openaimodel.py:204-244
+ *   stem / head conv                                      unet.py:522,719 ; openaimodel.py:522,688
+ *   Downsample.op (stride 2, pad 1)                       unet.py:135-139 ; openaimodel.py:152-156
+ *   Upsample: F.interpolate(nearest x2) + conv            unet.py:106-116 ; openaimodel.py:109-119 (fused: upsample=1)
+ *   AttentionBlock qkv / proj_out (1x1)                   unet.py:291-301 ; openaimodel.py:307-317
+ *   AE ResnetBlock / Downsample(pad (0,1)) / Upsample     ldm/modules/diffusionmodules/model.py:42-145
+ *   nn.Linear on token rows (SpatialTransformer)          ldm/modules/attention.py:152-215 (ksize=1)
+ *   th.cat([h, hs.pop()], 1) before a conv                unet.py:812 ; openaimodel.py:739 (fused: src2/C2)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t N, D, H, W;        /* input extent (before the fused x2 upsample); D = 1 for 2-D            */
+    int32_t C1, C2;            /* channels of src1 / src2 (C2 = 0: single source); padded, multiple of 32 */
+    int32_t Cout;              /* logical output channels                                                */
+    int32_t Cout_pad;          /* channel stride of `out` (multiple of 32 for bf16 outputs)              */
+    int32_t kd, kh, kw;        /* kernel extent per dim: 1 or 3 (kd = 1 for 2-D)                         */
+    int32_t stride;            /* 1 or 2 (applied to every dim with k > 1 or to all dims if k == 1)     */
+    int32_t pad;               /* leading zero padding per dim with k == 3 (1 = 'same'; 0 = AE Downsample) */
+    int32_t upsample;          /* 1: nearest-neighbour x2 on D(if kd==3),H,W is fused in front of the conv */
+    int32_t Do, Ho, Wo;        /* output extent                                                          */
+    int32_t out_dtype;         /* GG_BF16 or GG_F32                                                      */
+    int32_t prologue_act;      /* 0 none, 1: y = silu(x*gn_scale + gn_shift) applied while gathering    */
+    int32_t reserved;
+    const void *src1;          /* bf16 CL [N,D,H,W,C1]                                                   */
+    const void *src2;          /* bf16 CL [N,D,H,W,C2] or NULL                                           */
+    const void *weight;        /* packed by gg_conv_pack_weight                                          */
+    const float *bias;         /* fp32 [*, Cout_pad]; row n * bias_stride is added to sample n           */
+    int64_t bias_stride;       /* 0: one row shared by the batch (plain conv bias);
+                                  Cout_pad: per-sample rows (conv bias + timestep-embedding projection) */
+    const void *residual;      /* optional bf16 CL [N,Do,Ho,Wo,Cout_pad] added in the epilogue          */
+    void *out;                 /* CL [N,Do,Ho,Wo,Cout_pad]                                              */
+    const float *gn_scale;     /* fp32 [N, C1+C2] or NULL (see prologue_act)                             */
+    const float *gn_shift;
+} gg_conv_desc;
+
+/* Bytes of the packed weight for a conv with the given logical shape. */
+int64_t gg_conv_packed_weight_bytes(int32_t Cout, int32_t Cin_pad, int32_t ntaps);
+/* Repack an fp32 OI[D]HW weight (the checkpoint layout) into the MFMA tile order
+ * [Cout_pad/32][tap][Cin_pad/32][32 co][32 ci] bf16, zero-filling padded rows/cols.
+ * `w_f32` is a device pointer, logical shape [Cout, Cin, ntaps]; cin_map (host, may be NULL) is not used. */
+int gg_conv_pack_weight(const float *w_f32, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t ntaps,
+                        void *packed_bf16, void *stream);
+int gg_conv_forward(const gg_conv_desc *desc, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) statistics and fused normalise*affine(+SiLU).
+ * Replaces GroupNorm32 / Normalize + nn.SiLU / nonlinearity:
+ *   ccdm/.../unet_openai/nn.py:17-19,93-100 ; ldm/modules/diffusionmodules/util.py:199-216 ;
+ *   ldm/modules/diffusionmodules/model.py:33-39 ; ldm/modules/attention.py:76-77
+ * Two-source aware (fuses the skip concat).  Statistics are accumulated in fp32 per block and combined
+ * in fp64; results are written as per-(n,c) fp32 scale/shift so that y = x*scale + shift.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t gg_groupnorm_workspace_bytes(int32_t N, int64_t S, int32_t C);
+int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
+                       int32_t C_logical, const float *gamma, const float *beta, float eps,
+                       float *scale_out, float *shift_out, void *workspace, int64_t workspace_bytes, void *stream);
+/* y = act(x*scale[n,c] + shift[n,c]) ; act: 0 none, 1 SiLU.  out: bf16 CL [N,S,C1+C2]. */
+int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
+                       const float *scale, const float *shift, int32_t act, void *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention: out = softmax(scale * Q K^T) V, flash-style (no TxT buffer), MFMA 16x16x32 bf16, fp32 softmax.
+ * Replaces QKVAttentionLegacy (unet.py:334-360, openaimodel.py:349-371), CrossAttention
+ * (ldm/modules/attention.py:170-193) and AttnBlock2d's bmm/softmax/bmm (model.py:243-257).
+ * Element (n, t, h, d) of X in {Q,K,V,O} lives at X + ((n*T + t)*ld + h*hs + d).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t N, heads, head_dim;     /* head_dim in {32, 64, 128, 256, 384, 512}                          */
+    int32_t Tq, Tkv;
+    int64_t ldq, hsq, ldk, hsk, ldv, hsv, ldo, hso;
+    float scale;
+    int32_t reserved;
+    const void *q, *k, *v;          /* bf16 */
+    void *out;                      /* bf16 */
+} gg_attention_desc;
+int gg_attention_forward(const gg_attention_desc *desc, void *stream);
+
+/* LayerNorm over the last dim (nn.LayerNorm eps 1e-5, attention.py:203-205), bf16 rows -> bf16 rows. */
+int gg_layernorm(const void *x, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,
+                 void *out, void *stream);
+/* GEGLU: out[r, j] = h[r, j] * gelu_erf(h[r, inner + j]) (attention.py:37-44). */
+int gg_geglu(const void *h, int64_t rows, int32_t inner, void *out, void *stream);
+/* out = a + b (bf16, elementwise; residual adds of SpatialTransformer / attention). */
+int gg_add(const void *a, const void *b, int64_t n, void *out, void *stream);
+
+/* Small fp32 linear: out[m, o] = sum_i act(in[m, i]) * W[o, i] + b[o]; act: 0 none, 1 SiLU on the input.
+ * Replaces time_embed / emb_layers (unet.py:205-211,511-515 ; openaimodel.py:221-227,510-514). */
+int gg_linear_f32(const float *in, int32_t M, int32_t I, const float *W, const float *b, int32_t O,
+                  int32_t act_in, float *out, int64_t out_stride, void *stream);
+/* Sinusoidal embedding cos||sin (nn.py:103-121 ; util.py:151-171), t as fp32. */
+int gg_timestep_embedding(const float *t, int32_t M, int32_t dim, float max_period, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / dtype movers at the module boundary (NC[D]HW fp32 <-> CL bf16/fp32).
+ * ------------------------------------------------------------------------------------------------ */
+int gg_nchw_f32_to_cl_bf16(const float *src, int32_t N, int32_t C, int64_t S, void *dst, int32_t C_pad,
+                           int32_t c_offset, int32_t zero_fill, void *stream);
+int gg_cl_to_nchw_f32(const void *src, int32_t src_dtype, int32_t N, int32_t C, int64_t S, int32_t C_pad,
+                      float *dst, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CCDM categorical reverse step (per voxel, fully fused):
+ *   [softmax over K logits] -> theta_post_prob -> clamp 1e-12 -> renormalise -> argmax_k p_k/E_k
+ * Replaces nn.Softmax head (unet.py:715-721), DiffusionModel.theta_post_prob
+ * (ccdm/ddpm/models/diffusion_denoising.py:105-139), torch.clamp (:216) and
+ * OneHotCategoricalBCHW.sample/max_prob_sample/prob_sample (one_hot_categorical.py:30-55).
+ *   head       fp32 CL [M, head_stride]: probabilities (head_is_logits = 0) or logits (1)
+ *   xt         int32 [M] current labels
+ *   E          fp32 [M, K] exponential tape, or NULL
+ *   philox_seed/philox_offset: used when E == NULL and draw != 0 (counter-based Exp(1) generator)
+ *   draw       1: sample (t > 1); 0: argmax of the normalised posterior (t == 1)
+ *   scalars    device fp32[2] = {alphas[t-1] (0 at t==1), cumalphas[t-2] (1 at t==1)}
+ * Outputs: labels_out int32 [M] (may alias xt); probs_out fp32 [M, K] normalised posterior or NULL;
+ *          onehot_out bf16 CL [M, onehot_stride] (channels < K one-hot, rest untouched) or NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, int32_t head_is_logits, const int32_t *xt,
+                             const float *E, uint64_t philox_seed, const int64_t *philox_offset_dev, int32_t draw,
+                             const float *scalars_dev, int32_t K, int64_t M, int32_t *labels_out, float *probs_out,
+                             void *onehot_out, int32_t onehot_stride, void *stream);
+/* labels -> one-hot bf16 CL rows (x_T assembly; evaluator.py:135-136 + unet.py:774-775 concat with zeros). */
+int gg_labels_to_onehot(const int32_t *labels, int64_t M, int32_t K, void *onehot_out, int32_t stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DDIM update (ldm/models/diffusion/ddim.py:190-204), fp32, elementwise on CL tensors:
+ *   pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);  x_prev = sqrt(a_prev) pred_x0 + sqrt(1-a_prev-sigma^2) e + sigma*noise
+ *   scalars device fp32[4] = {a_t, a_prev, sigma_t, sqrt_one_minus_a_t};  noise may be NULL (treated as 0).
+ *   x [M, C] fp32 (in/out), eps [M, eps_stride] fp32, pred_x0_out optional;
+ *   unet_in optional bf16 CL [M, unet_in_stride]: channels [0, C) are refreshed with x_prev.
+ * ------------------------------------------------------------------------------------------------ */
+int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev,
+                 int64_t M, int32_t C, float *pred_x0_out, void *unet_in, int32_t unet_in_stride, void *stream);
+
+/* Slice normalisation (ds - min)/(max - min) over the whole tensor (latentdiffusion/sample_diffusion.py:222).
+ * workspace: >= 2 floats, zero-initialised by the call. */
+int gg_minmax_normalise(const float *src, int64_t n, float *dst, float *workspace2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUIDEGEN_HIP_H */

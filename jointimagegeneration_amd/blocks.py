@@ -1,0 +1,418 @@
+"""Network blocks of the two GuideGen UNets and the KL autoencoder, executed by the HIP engine.
+
+torch.nn.{ConvNd, GroupNorm, Linear, LayerNorm} objects appear here ONLY as parameter containers, so that
+`state_dict()` has exactly the reference's names and shapes (SURVEY.md 8b "state-dict surface"); their ATen
+`forward` is never called.  Each block's `run(...)` enqueues hand-written HIP kernels through `ops`.
+
+Reference blocks mirrored (file:line relative to the reference tree):
+  ResBlock / Upsample / Downsample / AttentionBlock / TimestepEmbedSequential
+      ccdm/ddpm/models/unet_openai/unet.py:70-360, latentdiffusion/ldm/modules/diffusionmodules/openaimodel.py:74-375
+  SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU
+      latentdiffusion/ldm/modules/attention.py:37-64,152-261
+  ResnetBlock / AttnBlock2d / Upsample / Downsample (AE)
+      latentdiffusion/ldm/modules/diffusionmodules/model.py:42-145,209-261
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import CL, pad32
+
+
+def conv_nd(dims, *a, **k):
+    return {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[dims](*a, **k)
+
+
+def zero_module(m):
+    """Reference initialisation of the last conv of each block (nn.py:68-74); only matters for fresh models."""
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+def _k3(w: torch.Tensor):
+    """(kd, kh, kw) of a conv weight; 1-D and 2-D kernels are left-padded with 1s."""
+    ks = tuple(w.shape[2:])
+    return (1,) * (3 - len(ks)) + ks
+
+
+class _Packed:
+    """Cache of kernel-friendly repacks (bf16 MFMA tile order, padded fp32 biases) keyed by parameter version."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, params, build):
+        ver = tuple((p.data_ptr(), p._version) for p in params if p is not None)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = build()
+        self.store[key] = (ver, val)
+        return val
+
+
+PACKED = _Packed()
+
+
+def packed_conv(mod: nn.Module, cin_pad: int, tag: str = ""):
+    """(packed bf16 weight, padded fp32 bias) of a conv/linear container for inputs with `cin_pad` channels."""
+    def build():
+        w = mod.weight
+        if w.ndim == 2:
+            w = w[:, :, None]
+        pw = ops.pack_conv_weight(w, cin_pad)
+        pb = ops.pad_bias(getattr(mod, "bias", None), w.shape[0], w.device)
+        return pw, pb
+    return PACKED.get((id(mod), cin_pad, tag), [mod.weight, getattr(mod, "bias", None)], build)
+
+
+def packed_cat(mods: List[nn.Module], cin_pad: int, tag: str):
+    """Several convs/linears sharing an input, fused along Cout (q|k|v projections)."""
+    def build():
+        ws = [m.weight if m.weight.ndim > 2 else m.weight[:, :, None] for m in mods]
+        ws = [w.reshape(w.shape[0], w.shape[1], -1) for w in ws]
+        w = torch.cat(ws, 0)
+        bs = [m.bias if getattr(m, "bias", None) is not None else torch.zeros(m.weight.shape[0], device=w.device) for m in mods]
+        pw = ops.pack_conv_weight(w, cin_pad)
+        pb = ops.pad_bias(torch.cat(bs, 0), w.shape[0], w.device)
+        return pw, pb
+    params = [m.weight for m in mods] + [getattr(m, "bias", None) for m in mods]
+    return PACKED.get((id(mods[0]), cin_pad, tag), params, build)
+
+
+def f32(p: torch.Tensor) -> torch.Tensor:
+    return p.detach().float().contiguous()
+
+
+def gn_silu(h: CL, norm: nn.GroupNorm, act: bool, src2: Optional[CL] = None) -> CL:
+    scale, shift = ops.groupnorm_stats(h, f32(norm.weight), f32(norm.bias), norm.eps, src2)
+    return ops.groupnorm_apply(h, scale, shift, act, src2)
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class GroupNorm32(nn.GroupNorm):
+    """Parameter container; statistics are fp32 in the HIP kernel as in the reference (nn.py:17-19)."""
+
+
+def normalization(ch):
+    return GroupNorm32(32, ch)
+
+
+# ------------------------------------------------------------------------------------------------ UNet blocks
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        if not use_conv:
+            raise NotImplementedError("Upsample without conv is not on the scoped path (conv_resample=True everywhere)")
+        self.conv = conv_nd(dims, channels, self.out_channels, 3, padding=1)
+
+    def run(self, h: CL) -> CL:
+        pw, pb = packed_conv(self.conv, h.Cpad)
+        return ops.conv(h, pw, pb, self.out_channels, k=_k3(self.conv.weight), stride=1, pad=1, upsample=True)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        if not use_conv:
+            raise NotImplementedError("avg-pool Downsample is not on the scoped path (conv_resample=True everywhere)")
+        self.op = conv_nd(dims, channels, self.out_channels, 3, stride=2, padding=1)
+
+    def run(self, h: CL) -> CL:
+        pw, pb = packed_conv(self.op, h.Cpad)
+        return ops.conv(h, pw, pb, self.out_channels, k=_k3(self.op.weight), stride=2, pad=1)
+
+
+class ResBlock(TimestepBlock):
+    """GN+SiLU -> conv3 (+timestep bias) -> GN+SiLU -> conv3 (+skip).  The timestep projection
+    `emb_layers` is folded into conv1's per-sample bias (SURVEY.md 2.3 "timestep-embed epilogue")."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down:
+            raise NotImplementedError("use_scale_shift_norm / resblock_updown are not used by any shipped config")
+        self.channels, self.emb_channels = channels, emb_channels
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def time_bias(self, emb: torch.Tensor, out: torch.Tensor) -> None:
+        """out[M, Cout_pad] = conv1.bias + Linear(SiLU(emb))  (unet.py:251-260)."""
+        lin, c1 = self.emb_layers[1], self.in_layers[2]
+        b = PACKED.get((id(self), "tb"), [lin.bias, c1.bias], lambda: (f32(lin.bias) + f32(c1.bias)))
+        ops.linear_f32(emb, f32(lin.weight), b, act_in=True, out=out)
+
+    def run(self, h: CL, tbias: torch.Tensor, src2: Optional[CL] = None) -> CL:
+        c1, c2 = self.in_layers[2], self.out_layers[3]
+        k = _k3(c1.weight)
+        cin_pad = h.Cpad + (src2.Cpad if src2 is not None else 0)
+        a = gn_silu(h, self.in_layers[0], True, src2)
+        pw1, _ = packed_conv(c1, cin_pad)
+        h1 = ops.conv(a, pw1, tbias, self.out_channels, k=k, bias_per_sample=True)
+        a2 = gn_silu(h1, self.out_layers[0], True)
+        if isinstance(self.skip_connection, nn.Identity):
+            res = h
+        else:
+            pws, pbs = packed_conv(self.skip_connection, cin_pad)
+            ks = _k3(self.skip_connection.weight)
+            res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
+        pw2, pb2 = packed_conv(c2, h1.Cpad)
+        return ops.conv(a2, pw2, pb2, self.out_channels, k=k, residual=res)
+
+
+class AttentionBlock(nn.Module):
+    """GN -> qkv 1x1 -> QKVAttentionLegacy -> proj 1x1 + x, with flash attention tiles (no TxT buffer)."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False, use_new_attention_order=False):
+        super().__init__()
+        if use_new_attention_order:
+            raise NotImplementedError("use_new_attention_order is not used by any shipped config")
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0, \
+                f"q,k,v channels {channels} is not divisible by num_head_channels {num_head_channels}"
+            self.num_heads = channels // num_head_channels
+        self.norm = normalization(channels)
+        self.qkv = conv_nd(1, channels, channels * 3, 1)
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+
+    def run(self, h: CL) -> CL:
+        Cc, nh = self.channels, self.num_heads
+        ch = Cc // nh
+        N, T = h.N, h.S
+        a = gn_silu(h, self.norm, False)
+        pw, pb = packed_conv(self.qkv, h.Cpad)
+        qkv = ops.conv(a, pw, pb, 3 * Cc, k=(1, 1, 1), pad=0)            # legacy order: head-major, q|k|v per head
+        att = torch.empty(tuple(h.t.shape[:4]) + (Cc,), dtype=torch.bfloat16, device=h.t.device)
+        ld = qkv.Cpad
+        ops.attention(qkv.t, qkv.t, qkv.t, att, N, nh, ch, T, T, (ld, 3 * ch), (ld, 3 * ch), (ld, 3 * ch), (Cc, ch),
+                      1.0 / math.sqrt(ch), q_off=0, k_off=ch, v_off=2 * ch)
+        pw2, pb2 = packed_conv(self.proj_out, Cc)
+        return ops.conv(CL(att, Cc), pw2, pb2, Cc, k=(1, 1, 1), pad=0, residual=h)
+
+
+# ------------------------------------------------------------------------------------------------ SpatialTransformer
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=True, dropout=0.0):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("non-gated FeedForward is not used by BasicTransformerBlock")
+        inner = int(dim * mult)
+        self.inner = inner
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim))
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.scale = dim_head ** -0.5
+        context_dim = context_dim or query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+
+    def run(self, xn: CL, context: Optional[CL], residual: CL) -> CL:
+        """to_out(attn(to_q(xn), to_k(ctx), to_v(ctx))) + residual; xn/context are token rows as CL [N,1,1,T,C]."""
+        N, T = xn.N, xn.S
+        inner, hd = self.inner, self.dim_head
+        if context is None:
+            pw, pb = packed_cat([self.to_q, self.to_k, self.to_v], xn.Cpad, "qkv")
+            qkv = ops.conv(xn, pw, pb, 3 * inner, k=(1, 1, 1), pad=0)
+            q = k = v = qkv.t
+            ldq = ldk = qkv.Cpad
+            qo, ko, vo, Tkv = 0, inner, 2 * inner, T
+        else:
+            pwq, pbq = packed_conv(self.to_q, xn.Cpad)
+            qc = ops.conv(xn, pwq, pbq, inner, k=(1, 1, 1), pad=0)
+            pwk, pbk = packed_cat([self.to_k, self.to_v], context.Cpad, "kv")
+            kvc = ops.conv(context, pwk, pbk, 2 * inner, k=(1, 1, 1), pad=0)
+            q, k, v = qc.t, kvc.t, kvc.t
+            ldq, ldk = qc.Cpad, kvc.Cpad
+            qo, ko, vo, Tkv = 0, 0, inner, context.S
+        att = torch.empty(tuple(xn.t.shape[:4]) + (inner,), dtype=torch.bfloat16, device=xn.t.device)
+        ops.attention(q, k, v, att, N, self.heads, hd, T, Tkv, (ldq, hd), (ldk, hd), (ldk, hd), (inner, hd), self.scale,
+                      q_off=qo, k_off=ko, v_off=vo)
+        pwo, pbo = packed_conv(self.to_out[0], inner)
+        return ops.conv(CL(att, inner), pwo, pbo, self.to_out[0].weight.shape[0], k=(1, 1, 1), pad=0, residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    def _ln(self, x: CL, ln: nn.LayerNorm) -> CL:
+        return CL(ops.layernorm(x.t, f32(ln.weight), f32(ln.bias), ln.eps), x.C)
+
+    def run(self, x: CL, context: Optional[CL]) -> CL:
+        x = self.attn1.run(self._ln(x, self.norm1), None, x)
+        x = self.attn2.run(self._ln(x, self.norm2), context, x)
+        y = self._ln(x, self.norm3)
+        proj, lin2 = self.ff.net[0].proj, self.ff.net[2]
+        pw, pb = packed_conv(proj, y.Cpad)
+        hcl = ops.conv(y, pw, pb, proj.weight.shape[0], k=(1, 1, 1), pad=0)
+        gg = ops.geglu(hcl.t, self.ff.inner)
+        pw2, pb2 = packed_conv(lin2, self.ff.inner)
+        return ops.conv(CL(gg, self.ff.inner), pw2, pb2, lin2.weight.shape[0], k=(1, 1, 1), pad=0, residual=x)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.inner = inner
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim) for _ in range(depth)])
+        self.proj_out = zero_module(nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0))
+
+    def run(self, h: CL, context: Optional[CL]) -> CL:
+        a = gn_silu(h, self.norm, False)
+        pw, pb = packed_conv(self.proj_in, h.Cpad)
+        x = ops.conv(a, pw, pb, self.inner, k=(1, 1, 1), pad=0)          # 'b c h w -> b (h w) c' is free in CL
+        for blk in self.transformer_blocks:
+            x = blk.run(x, context)
+        pw2, pb2 = packed_conv(self.proj_out, x.Cpad)
+        return ops.conv(x, pw2, pb2, self.in_channels, k=(1, 1, 1), pad=0, residual=h)
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Dispatches (h, time-bias, context, skip) to the children that take them (unet.py:70-84)."""
+
+    def run(self, h: CL, tbias_of, context: Optional[CL], skip: Optional[CL] = None) -> CL:
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                h = layer.run(h, tbias_of(layer), skip)
+                skip = None
+            elif isinstance(layer, SpatialTransformer):
+                h = layer.run(h, context)
+            elif isinstance(layer, (AttentionBlock, Upsample, Downsample)):
+                h = layer.run(h)
+            elif isinstance(layer, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+                pw, pb = packed_conv(layer, h.Cpad)
+                h = ops.conv(h, pw, pb, layer.weight.shape[0], k=_k3(layer.weight), pad=1)
+            else:
+                raise TypeError(f"no HIP execution rule for {type(layer).__name__}")
+        if skip is not None:
+            raise RuntimeError("skip tensor was not consumed by a ResBlock")
+        return h
+
+
+# ------------------------------------------------------------------------------------------------ AE blocks
+def Normalize(in_channels, num_groups=32):
+    return nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class AEUpsample(nn.Module):
+    def __init__(self, in_channels, with_conv, dims=2):
+        super().__init__()
+        assert with_conv and dims == 2
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def run(self, h: CL) -> CL:
+        pw, pb = packed_conv(self.conv, h.Cpad)
+        return ops.conv(h, pw, pb, self.conv.weight.shape[0], k=(1, 3, 3), upsample=True)
+
+
+class AEDownsample(nn.Module):
+    """pad (0,1,0,1) then stride-2 valid conv (model.py:75-79) = conv with leading pad 0, trailing pad 1."""
+
+    def __init__(self, in_channels, with_conv, dims=2):
+        super().__init__()
+        assert with_conv and dims == 2
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+
+    def run(self, h: CL) -> CL:
+        pw, pb = packed_conv(self.conv, h.Cpad)
+        return ops.conv(h, pw, pb, self.conv.weight.shape[0], k=(1, 3, 3), stride=2, pad=0)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0, dims=2):
+        super().__init__()
+        assert dims == 2 and temb_channels == 0 and not conv_shortcut
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1, 1, 0)
+
+    def run(self, h: CL) -> CL:
+        a = gn_silu(h, self.norm1, True)
+        pw1, pb1 = packed_conv(self.conv1, h.Cpad)
+        h1 = ops.conv(a, pw1, pb1, self.out_channels, k=(1, 3, 3))
+        a2 = gn_silu(h1, self.norm2, True)
+        res = h
+        if self.in_channels != self.out_channels:
+            pws, pbs = packed_conv(self.nin_shortcut, h.Cpad)
+            res = ops.conv(h, pws, pbs, self.out_channels, k=(1, 1, 1), pad=0)
+        pw2, pb2 = packed_conv(self.conv2, h1.Cpad)
+        return ops.conv(a2, pw2, pb2, self.out_channels, k=(1, 3, 3), residual=res)
+
+
+class AttnBlock2d(nn.Module):
+    """Single-head attention over c channels, scale c^-1/2 (model.py:209-261); q|k|v fused into one 1x1 conv."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, 1, 1, 0)
+        self.k = nn.Conv2d(in_channels, in_channels, 1, 1, 0)
+        self.v = nn.Conv2d(in_channels, in_channels, 1, 1, 0)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, 1, 1, 0)
+
+    def run(self, h: CL) -> CL:
+        Cc = self.in_channels
+        N, T = h.N, h.S
+        a = gn_silu(h, self.norm, False)
+        pw, pb = packed_cat([self.q, self.k, self.v], h.Cpad, "qkv")
+        qkv = ops.conv(a, pw, pb, 3 * Cc, k=(1, 1, 1), pad=0)
+        att = torch.empty(tuple(h.t.shape[:4]) + (Cc,), dtype=torch.bfloat16, device=h.t.device)
+        ld = qkv.Cpad
+        ops.attention(qkv.t, qkv.t, qkv.t, att, N, 1, Cc, T, T, (ld, Cc), (ld, Cc), (ld, Cc), (Cc, Cc), int(Cc) ** -0.5,
+                      q_off=0, k_off=Cc, v_off=2 * Cc)
+        pw2, pb2 = packed_conv(self.proj_out, Cc)
+        return ops.conv(CL(att, Cc), pw2, pb2, Cc, k=(1, 1, 1), pad=0, residual=h)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libguidegen_hip.so for gfx950 in-tree (the .so travels to the GPU box with the snapshot).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -fno-gpu-rdc"
+OBJS=()
+for f in gg_conv gg_conv_halo gg_norm gg_attn gg_sampler; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gg_common.h -nt $f.o ] || [ ../../include/guidegen_hip.h -nt $f.o ]; then
+    echo "hipcc $f.hip"
+    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  fi
+  OBJS+=($f.o)
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libguidegen_hip.so "${OBJS[@]}"
+echo "built $(pwd)/libguidegen_hip.so"

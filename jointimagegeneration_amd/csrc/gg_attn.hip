@@ -1,0 +1,190 @@
+// Flash-style attention on MFMA 16x16x32 bf16 (gfx950): out = softmax(scale * Q K^T) V without a TxT buffer.
+//
+// Orientation (per wave = 16 queries, per step = 32 keys), chosen so that no score ever changes lane:
+//   S^T[key, q]  = K Q^T      A = K rows from LDS (row = key, k = d), B = Q rows held in registers (col = q)
+//                             -> lane (q = l&15, g = l>>4) holds keys {4g..4g+3} and {16+4g..16+4g+3}
+//   softmax over keys         = in-lane over 8 values + two xor-shuffles (lanes l^16, l^32); state (m, l) per lane
+//   O^T[d, q]   += V^T P^T    B = P^T straight from the score registers (k-slot (g,j) <-> key 4g+j | 16+4g+j-4),
+//                             A = V^T via ds_read_b64_tr_b16 on the row-major V tile with the SAME k-slot map
+//   epilogue                  lane holds 4 consecutive d of one query -> 8-byte stores
+#include "gg_common.h"
+
+struct AttnParams {
+    int N, heads, Tq, Tkv;
+    long long ldq, hsq, ldk, hsk, ldv, hsv, ldo, hso;
+    float scale_log2;
+    const bf16_t *q, *k, *v;
+    bf16_t *out;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// chunk (16 B) swizzle inside a row of CH chunks so that 16 consecutive rows at one column chunk hit distinct banks
+template <int CH>
+__device__ __forceinline__ int swz_row(int row, int chunk)
+{
+    if constexpr (CH == 4) return chunk ^ ((0 - (row >> 2)) & 3);
+    else if constexpr (CH == 8) return chunk ^ ((row >> 1) & 7);
+    else return chunk ^ (row & 15);
+}
+
+template <int D, int KT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
+{
+    constexpr int CH = D / 8;          // 16-byte chunks per row
+    constexpr int ROWB = D * 2;
+    constexpr int KS = D / 32;         // k-steps of the S^T product
+    constexpr int DT = D / 16;         // d tiles of O^T
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * ROWB];
+    char *ksm = smem, *vsm = smem + KT * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    const int n = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+
+    // Q fragments (B operand: col = query fr, k = 8g + j)
+    bf16x8 qf[KS];
+    {
+        int qi = q0 + fr;
+        if (qi >= p.Tq) qi = p.Tq - 1;
+        const bf16_t *qp = p.q + ((long long)n * p.Tq + qi) * p.ldq + (long long)h * p.hsq + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qp + ks * 32);
+    }
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const bf16_t *kbase = p.k + (long long)n * p.Tkv * p.ldk + (long long)h * p.hsk;
+    const bf16_t *vbase = p.v + (long long)n * p.Tkv * p.ldv + (long long)h * p.hsv;
+
+    for (int key0 = 0; key0 < p.Tkv; key0 += KT) {
+        __syncthreads();   // previous tile fully consumed
+        for (int i = tid; i < KT * CH; i += 256) {
+            int r = i / CH, c = i - r * CH;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (key0 + r < p.Tkv) {
+                kv = *reinterpret_cast<const u32x4 *>(kbase + (long long)(key0 + r) * p.ldk + c * 8);
+                vv = *reinterpret_cast<const u32x4 *>(vbase + (long long)(key0 + r) * p.ldv + c * 8);
+            }
+            int off = r * ROWB + swz_row<CH>(r, c) * 16;
+            *reinterpret_cast<u32x4 *>(ksm + off) = kv;
+            *reinterpret_cast<u32x4 *>(vsm + off) = vv;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            if (key0 + sub * 32 >= p.Tkv) break;
+            // ---- S^T for 32 keys: two 16-key tiles
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int r = sub * 32 + kt * 16 + fr;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ksm + r * ROWB + swz_row<CH>(r, ks * 4 + g) * 16);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax (fp32, base-2)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = key0 + sub * 32 + kt * 16 + 4 * g + r;
+                    float v = (key < p.Tkv) ? s[kt][r] * p.scale_log2 : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);
+            float rs = 0.f;
+            bf16x8 pf;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = exp2f(s[kt][r] - m_new);
+                    rs += pv;
+                    pf[kt * 4 + r] = (bf16_t)pv;
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+            // ---- O^T += V^T P^T
+            const int qrow = fr >> 2, pcol = fr & 3;
+            const int vr0 = sub * 32 + 4 * g + qrow, vr1 = vr0 + 16;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int chunk = 2 * dt + (pcol >> 1);
+                const int sub8 = (pcol & 1) * 8;
+                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(vsm + vr0 * ROWB + swz_row<CH>(vr0, chunk) * 16 + sub8));
+                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(vsm + vr1 * ROWB + swz_row<CH>(vr1, chunk) * 16 + sub8));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                f32x4 acc = o[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc, 0, 0, 0);
+            }
+        }
+    }
+
+    const int qi = q0 + fr;
+    if (qi < p.Tq) {
+        const float inv = 1.0f / l_run;
+        bf16_t *op = p.out + ((long long)n * p.Tq + qi) * p.ldo + (long long)h * p.hso + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16x4 ob;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)(o[dt][r] * inv);
+            *reinterpret_cast<bf16x4 *>(op + dt * 16) = ob;
+        }
+    }
+}
+
+template <int D, int KT>
+static int launch_attn(const AttnParams &p, hipStream_t stream)
+{
+    dim3 grid((unsigned)((p.Tq + 63) / 64), (unsigned)p.heads, (unsigned)p.N);
+    hipLaunchKernelGGL((attn_kernel<D, KT>), grid, dim3(256), 0, stream, p);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" int gg_attention_forward(const gg_attention_desc *d, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !d->q || !d->k || !d->v || !d->out) GG_FAIL(GG_ERR_BAD_SHAPE, "attention: null pointer");
+    if (d->N <= 0 || d->heads <= 0 || d->Tq <= 0 || d->Tkv <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "attention: empty extent");
+    auto al8 = [](long long x) { return (x % 8) == 0; };
+    if (!al8(d->ldq) || !al8(d->hsq) || !al8(d->ldk) || !al8(d->hsk) || !al8(d->ldv) || !al8(d->hsv) || !al8(d->ldo) || !al8(d->hso))
+        GG_FAIL(GG_ERR_BAD_SHAPE, "attention: strides must be multiples of 8 elements (16-byte rows)");
+    AttnParams p;
+    p.N = d->N; p.heads = d->heads; p.Tq = d->Tq; p.Tkv = d->Tkv;
+    p.ldq = d->ldq; p.hsq = d->hsq; p.ldk = d->ldk; p.hsk = d->hsk; p.ldv = d->ldv; p.hsv = d->hsv; p.ldo = d->ldo; p.hso = d->hso;
+    p.scale_log2 = d->scale * 1.4426950408889634f;
+    p.q = (const bf16_t *)d->q; p.k = (const bf16_t *)d->k; p.v = (const bf16_t *)d->v; p.out = (bf16_t *)d->out;
+    switch (d->head_dim) {
+        case 32: return launch_attn<32, 128>(p, stream);
+        case 64: return launch_attn<64, 64>(p, stream);
+        case 128: return launch_attn<128, 64>(p, stream);
+        case 256: return launch_attn<256, 32>(p, stream);
+        case 384: return launch_attn<384, 32>(p, stream);
+        case 512: return launch_attn<512, 32>(p, stream);
+        default: GG_FAIL(GG_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128,256,384,512}", d->head_dim);
+    }
+}

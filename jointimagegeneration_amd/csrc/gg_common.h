@@ -1,0 +1,52 @@
+// Shared device/host helpers for libguidegen_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/guidegen_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define GG_WAVE 64
+
+// thread-local error message (error convention)
+void gg_set_error(const char *fmt, ...);
+
+#define GG_FAIL(code, ...)            \
+    do {                              \
+        gg_set_error(__VA_ARGS__);    \
+        return (code);                \
+    } while (0)
+
+#define GG_CHECK_LAUNCH()                                                              \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) GG_FAIL(GG_ERR_HIP, "HIP launch: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+__device__ __forceinline__ float gg_silu(float y) { return y / (1.0f + __expf(-y)); }
+
+__device__ __forceinline__ f32x8 gg_bf16x8_to_f32(bf16x8 v)
+{
+    f32x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+    return r;
+}
+__device__ __forceinline__ bf16x8 gg_f32_to_bf16x8(f32x8 v)
+{
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    return r;
+}
+
+static inline int gg_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,324 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (bf16 in, fp32 accumulate).
+//
+// GEMM view (operands swapped so that each lane ends up holding 4 consecutive output CHANNELS of one
+// output position -> 8-byte bf16 stores along the contiguous channel axis):
+//     D[co, m] = sum_{tap, ci}  Wp[co, tap, ci] * X[pos(m) + tap, ci]
+//   MFMA A operand  = weight rows  (row = co,  k = ci)   16 B per lane from the packed weight tile
+//   MFMA B operand  = activation   (col = m,   k = ci)   16 B per lane from the gathered position row
+//
+// Two kernels share the MFMA/epilogue code:
+//   conv_gather  : generic. Rows of the activation tile are gathered per (tap, 32-channel chunk) from HBM/L2
+//                  with bounds-checked 16-byte loads (zero padding, stride 2, fused nearest x2 upsample,
+//                  two-source concat, optional GroupNorm*SiLU prologue), staged through registers into a
+//                  swizzled, double-buffered LDS tile.
+//   conv_halo    : fast path for 3x3(x3) stride-1 convs on large extents (see gg_conv_halo.hip).
+#include "gg_common.h"
+
+struct ConvParams {
+    int N, D, H, W, C1, C2, Cout, Cout_pad;
+    int kd, kh, kw, stride, pad, upsample;
+    int Do, Ho, Wo, out_dtype, prologue_act;
+    int nchunk1, nchunk, ntaps;
+    long long M;              // N*Do*Ho*Wo
+    long long bias_stride;
+    const bf16_t *src1, *src2, *weight, *residual;
+    const float *bias, *gn_scale, *gn_shift;
+    void *out;
+};
+
+// 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = l&15, chunk = l>>4):
+// conflict-free for 16 consecutive rows (derivation in DESIGN.md, "LDS images").
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
+{
+    constexpr int BM = 128;
+    constexpr int XBYTES = BM * 64;
+    constexpr int WBYTES = NT * 32 * 64;
+    constexpr int STAGE = XBYTES + WBYTES;
+    constexpr int WITER = (NT * 128 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int g0 = blockIdx.y * NT;
+
+    // ---- per-thread gather duties: rows r and r+64, 16-byte piece q of the 64-byte channel chunk
+    const int xq = tid & 3;
+    int bn[2], bd[2], bh[2], bw[2];
+    bool rv[2];
+    const long long osp = (long long)p.Do * p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long long m = m0 + (tid >> 2) + 64 * i;
+        rv[i] = m < p.M;
+        if (!rv[i]) m = 0;
+        int n = (int)(m / osp);
+        long long r = m - (long long)n * osp;
+        int od = (int)(r / ((long long)p.Ho * p.Wo));
+        r -= (long long)od * p.Ho * p.Wo;
+        int oh = (int)(r / p.Wo);
+        int ow = (int)(r - (long long)oh * p.Wo);
+        bn[i] = n;
+        // coordinates in the (possibly upsampled) input frame of tap (0,0,0)
+        bd[i] = (p.kd == 1) ? od * (p.upsample ? 1 : p.stride) : od * p.stride - p.pad;
+        bh[i] = (p.kh == 1) ? oh * (p.upsample ? 1 : p.stride) : oh * p.stride - p.pad;
+        bw[i] = (p.kw == 1) ? ow * (p.upsample ? 1 : p.stride) : ow * p.stride - p.pad;
+    }
+    const int upD = (p.upsample && p.kd == 3) ? 1 : 0;  // 2-D convs never upsample the dummy D axis
+    const int upHW = p.upsample ? 1 : 0;
+    const int limD = p.D << upD, limH = p.H << upHW, limW = p.W << upHW;
+
+    u32x4 xreg[2];
+    u32x4 wreg[WITER];
+
+    int chunk = 0, tkd = 0, tkh = 0, tkw = 0, tap = 0;  // k-step counters for the NEXT global load
+
+    auto load_regs = [&]() {
+        const bool second = chunk >= p.nchunk1;
+        const bf16_t *src = second ? p.src2 : p.src1;
+        const int Cs = second ? p.C2 : p.C1;
+        const int cc = second ? chunk - p.nchunk1 : chunk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ud = bd[i] + tkd, uh = bh[i] + tkh, uw = bw[i] + tkw;
+            bool ok = rv[i] && ud >= 0 && ud < limD && uh >= 0 && uh < limH && uw >= 0 && uw < limW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                int id = ud >> upD, ih = uh >> upHW, iw = uw >> upHW;
+                long long off = ((((long long)bn[i] * p.D + id) * p.H + ih) * p.W + iw) * Cs + cc * 32 + xq * 8;
+                v = *reinterpret_cast<const u32x4 *>(src + off);
+                if (p.prologue_act) {
+                    const long long so = (long long)bn[i] * (p.C1 + p.C2) + chunk * 32 + xq * 8;
+                    f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so);
+                    f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so + 4);
+                    f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so);
+                    f32x4 h1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
+                    bf16x8 xb = __builtin_bit_cast(bf16x8, v);
+                    bf16x8 yb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        yb[j] = (bf16_t)gg_silu((float)xb[j] * s0[j] + h0[j]);
+                        yb[j + 4] = (bf16_t)gg_silu((float)xb[j + 4] * s1[j] + h1[j]);
+                    }
+                    v = __builtin_bit_cast(u32x4, yb);
+                }
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WITER; ++j) {
+            int i = tid + 256 * j;
+            if (i < NT * 128) {
+                int g = i >> 7, pc = i & 127;
+                long long off = ((((long long)(g0 + g) * p.ntaps + tap) * p.nchunk + chunk) << 10) + pc * 8;
+                wreg[j] = *reinterpret_cast<const u32x4 *>(p.weight + off);
+            }
+        }
+        // advance (chunk outer, tap inner)
+        ++tap;
+        if (++tkw == p.kw) {
+            tkw = 0;
+            if (++tkh == p.kh) {
+                tkh = 0;
+                if (++tkd == p.kd) { tkd = 0; tap = 0; ++chunk; }
+            }
+        }
+    };
+
+    auto write_lds = [&](int buf) {
+        char *xb = smem + buf * STAGE;
+        char *wb = xb + XBYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = (tid >> 2) + 64 * i;
+            *reinterpret_cast<u32x4 *>(xb + r * 64 + swz64(r, xq) * 16) = xreg[i];
+        }
+#pragma unroll
+        for (int j = 0; j < WITER; ++j) {
+            int i = tid + 256 * j;
+            if (i < NT * 128) {
+                int r = i >> 2, q = i & 3;
+                *reinterpret_cast<u32x4 *>(wb + r * 64 + swz64(r, q) * 16) = wreg[j];
+            }
+        }
+    };
+
+    f32x4 acc[2][2 * NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+        const char *xb = smem + buf * STAGE;
+        const char *wb = xb + XBYTES;
+        bf16x8 xf[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            int r = wave * 32 + pt * 16 + fr;
+            xf[pt] = *reinterpret_cast<const bf16x8 *>(xb + r * 64 + swz64(r, fq) * 16);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2 * NT; ++ct) {
+            int r = ct * 16 + fr;
+            bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+                acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[pt], acc[pt][ct], 0, 0, 0);
+        }
+    };
+
+    const int KS = p.ntaps * p.nchunk;
+    load_regs();
+    write_lds(0);
+    __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < KS) load_regs();
+        compute(cur);
+        if (ks + 1 < KS) write_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias[n] (+ residual) -> bf16 / fp32, 4 consecutive channels per lane
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        long long m = m0 + wave * 32 + pt * 16 + fr;
+        if (m >= p.M) continue;
+        int n = (int)(m / osp);
+        const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
+#pragma unroll
+        for (int ct = 0; ct < 2 * NT; ++ct) {
+            int co = (g0 * 32) + ct * 16 + fq * 4;
+            f32x4 v = acc[pt][ct];
+            if (brow) {
+                f32x4 b = *reinterpret_cast<const f32x4 *>(brow + co);
+                v += b;
+            }
+            long long o = m * p.Cout_pad + co;
+            if (p.residual) {
+                bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co + j >= p.Cout) v[j] = 0.f;
+            if (p.out_dtype == GG_F32) {
+                *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+            } else {
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+__global__ void conv_pack_weight_kernel(const float *__restrict__ w, int Cout, int Cin, int Cin_pad, int ntaps,
+                                        int Cout_pad, bf16_t *__restrict__ dst)
+{
+    const int nchunk = Cin_pad >> 5;
+    const long long total = (long long)Cout_pad * ntaps * Cin_pad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int cil = (int)(i & 31);
+        int col = (int)((i >> 5) & 31);
+        long long t = i >> 10;
+        int chunk = (int)(t % nchunk);
+        t /= nchunk;
+        int tap = (int)(t % ntaps);
+        int g = (int)(t / ntaps);
+        int co = g * 32 + col, ci = chunk * 32 + cil;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * ntaps + tap];
+        dst[i] = (bf16_t)v;
+    }
+}
+
+extern "C" int64_t gg_conv_packed_weight_bytes(int32_t Cout, int32_t Cin_pad, int32_t ntaps)
+{
+    int64_t cp = ((int64_t)Cout + 31) / 32 * 32;
+    return cp * ntaps * Cin_pad * 2;
+}
+
+extern "C" int gg_conv_pack_weight(const float *w, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t ntaps,
+                                   void *packed, void *stream)
+{
+    if (Cin_pad % 32 || Cin > Cin_pad || Cout <= 0 || ntaps <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "pack_weight: bad shape");
+    int Cout_pad = (Cout + 31) / 32 * 32;
+    long long total = (long long)Cout_pad * ntaps * Cin_pad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, Cin_pad,
+                       ntaps, Cout_pad, (bf16_t *)packed);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// halo fast path (gg_conv_halo.hip); returns GG_ERR_UNSUPPORTED when the shape is outside its envelope
+int gg_conv_halo_try(const ConvParams &p, hipStream_t stream);
+
+template <int NT>
+static int launch_gather(const ConvParams &p, hipStream_t stream)
+{
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.Cout_pad / (32 * NT)));
+    hipLaunchKernelGGL(conv_gather_kernel<NT>, grid, dim3(256), 0, stream, p);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: null desc");
+    if (d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->C2 < 0) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: C1/C2 must be multiples of 32 (got %d, %d)", d->C1, d->C2);
+    if (d->Cout_pad % 32 || d->Cout > d->Cout_pad || d->Cout <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: bad Cout/Cout_pad %d/%d", d->Cout, d->Cout_pad);
+    auto okk = [](int k) { return k == 1 || k == 3; };
+    if (!okk(d->kd) || !okk(d->kh) || !okk(d->kw)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: kernel extent must be 1 or 3");
+    if (d->stride != 1 && d->stride != 2) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: stride must be 1 or 2");
+    if (d->upsample && d->stride != 1) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: upsample with stride");
+    if (d->out_dtype != GG_BF16 && d->out_dtype != GG_F32) GG_FAIL(GG_ERR_BAD_DTYPE, "conv: out dtype");
+    if (!d->src1 || !d->weight || !d->out || (d->C2 && !d->src2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: null pointer");
+    if (d->prologue_act && (!d->gn_scale || !d->gn_shift)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: prologue without scale/shift");
+    if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: empty extent");
+    // output extent must match the conv arithmetic (what nn.ConvNd / F.interpolate would produce)
+    auto expect = [&](int in, int k, int up) {
+        int e = up ? in * 2 : in;
+        if (k == 1) return (d->upsample && !up) ? e : (e - 1) / d->stride + 1;
+        // pad lo = d->pad, pad hi chosen so that 'same' (pad 1) or AE (0,1) arithmetic holds
+        return (d->stride == 1) ? e + 2 * d->pad - 2 : (d->pad == 1 ? (e + 2 - 3) / 2 + 1 : (e + 1 - 3) / 2 + 1);
+    };
+    const int upD = d->upsample && d->kd == 3, upHW = d->upsample;
+    if (d->Do != expect(d->D, d->kd, upD) || d->Ho != expect(d->H, d->kh, upHW) || d->Wo != expect(d->W, d->kw, upHW))
+        GG_FAIL(GG_ERR_BAD_SHAPE, "conv: output extent (%d,%d,%d) inconsistent with input (%d,%d,%d) k=(%d,%d,%d) stride %d pad %d up %d",
+                d->Do, d->Ho, d->Wo, d->D, d->H, d->W, d->kd, d->kh, d->kw, d->stride, d->pad, d->upsample);
+
+    ConvParams p;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Cout = d->Cout; p.Cout_pad = d->Cout_pad;
+    p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.upsample = d->upsample;
+    p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.prologue_act = d->prologue_act;
+    p.nchunk1 = d->C1 / 32; p.nchunk = (d->C1 + d->C2) / 32; p.ntaps = d->kd * d->kh * d->kw;
+    p.M = (long long)d->N * d->Do * d->Ho * d->Wo;
+    p.bias_stride = d->bias_stride;
+    p.src1 = (const bf16_t *)d->src1; p.src2 = (const bf16_t *)d->src2; p.weight = (const bf16_t *)d->weight;
+    p.residual = (const bf16_t *)d->residual; p.bias = d->bias; p.gn_scale = d->gn_scale; p.gn_shift = d->gn_shift;
+    p.out = d->out;
+
+    int rc = gg_conv_halo_try(p, stream);
+    if (rc != GG_ERR_UNSUPPORTED) return rc;
+
+    const int G = p.Cout_pad / 32;
+    if (G % 4 == 0) return launch_gather<4>(p, stream);
+    if (G % 5 == 0) return launch_gather<5>(p, stream);
+    if (G % 3 == 0) return launch_gather<3>(p, stream);
+    if (G % 2 == 0) return launch_gather<2>(p, stream);
+    return launch_gather<1>(p, stream);
+}

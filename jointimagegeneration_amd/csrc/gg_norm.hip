@@ -1,0 +1,325 @@
+// GroupNorm(32) statistics + fused normalise*affine(+SiLU), LayerNorm, GEGLU, add. HBM-bound kernels:
+// 16-byte (8 x bf16) accesses per lane, fp32 math, two-source aware (fused skip concat).
+#include "gg_common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// Stage 1: per-block partial sums. grid = (nblk, N). Block b of sample n owns rows [b*rpb, (b+1)*rpb).
+// A thread always sees the same 8-channel piece (piece = tid % P), so its 8+8 running sums stay in registers.
+// Partials are written as part[n][b][c][2] (fp32: sum, sumsq per CHANNEL) -- deterministic, no atomics.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t *__restrict__ s1, int C1,
+                                                         const bf16_t *__restrict__ s2, int C2, long long S,
+                                                         long long rows_per_block, float *__restrict__ part)
+{
+    const int C = C1 + C2;
+    const int P = C >> 3;                     // 16-byte pieces per row
+    const int rpi = blockDim.x / P;           // rows per iteration
+    const int tid = threadIdx.x;
+    const int piece = tid % P, rsub = tid / P;
+    const int n = blockIdx.y;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > S) r1 = S;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = sq[j] = 0.f;
+    if (rsub < rpi) {
+        const int c0 = piece * 8;
+        const bool second = c0 >= C1;
+        const bf16_t *base = second ? s2 + (long long)n * S * C2 + (c0 - C1) : s1 + (long long)n * S * C1 + c0;
+        const int Cs = second ? C2 : C1;
+        for (long long r = r0 + rsub; r < r1; r += rpi) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(base + r * Cs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j];
+                sum[j] += f;
+                sq[j] += f * f;
+            }
+        }
+    }
+    // reduce the rpi row-slots of every piece through LDS
+    extern __shared__ float red[];            // [256][16]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid * 16 + j] = sum[j];
+        red[tid * 16 + 8 + j] = sq[j];
+    }
+    __syncthreads();
+    if (tid < P) {
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = 0.f;
+        for (int k = 0; k < rpi; ++k)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] += red[(k * P + tid) * 16 + j];
+        float *dst = part + (((long long)n * gridDim.x + blockIdx.x) * C + tid * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dst[2 * j] = a[j];
+            dst[2 * j + 1] = a[8 + j];
+        }
+    }
+}
+
+// Stage 2: one block per (n): combine partials in fp64 (fixed order), per-group mean/rstd, fold gamma/beta into
+// per-(n,c) scale/shift:  y = x*scale + shift  with scale = rstd*gamma, shift = beta - mean*rstd*gamma.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part, int nblk, int C, int C_logical,
+                                                          long long S, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int n = blockIdx.x;
+    const int cpg = C_logical / 32;
+    __shared__ double csum[2048], csq[2048];
+    __shared__ float gmean[32], grstd[32];
+    // each thread owns channels c = tid, tid+256, ...: fixed-order fp64 combine of the block partials
+    for (int c = threadIdx.x; c < C_logical; c += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            const float *q = part + (((long long)n * nblk + k) * C + c) * 2;
+            a += (double)q[0];
+            b += (double)q[1];
+        }
+        csum[c] = a;
+        csq[c] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            a += csum[threadIdx.x * cpg + j];
+            b += csq[threadIdx.x * cpg + j];
+        }
+        double cnt = (double)S * cpg;
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmean[threadIdx.x] = (float)mean;
+        grstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sc = 0.f, sh = 0.f;
+        if (c < C_logical) {
+            int g = c / cpg;
+            sc = grstd[g] * gamma[c];
+            sh = beta[c] - gmean[g] * sc;
+        }
+        scale[(long long)n * C + c] = sc;
+        shift[(long long)n * C + c] = sh;
+    }
+}
+
+extern "C" int64_t gg_groupnorm_workspace_bytes(int32_t N, int64_t S, int32_t C)
+{
+    (void)S;
+    return (int64_t)N * 1024 * C * 2 * 4;   // up to 1024 partial blocks per sample
+}
+
+static int gn_nblk(int N, long long S, int C)
+{
+    // enough blocks to fill the chip (256 CUs x ~8), at least ~64 rows per block
+    long long want = (2048 + N - 1) / N;
+    long long maxb = (S + 63) / 64;
+    long long nb = want < maxb ? want : maxb;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    (void)C;
+    return (int)nb;
+}
+
+extern "C" int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
+                                  int32_t C_logical, const float *gamma, const float *beta, float eps, float *scale_out,
+                                  float *shift_out, void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int C = C1 + C2;
+    if (C1 <= 0 || C1 % 32 || C2 % 32 || C2 < 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: C1/C2 must be multiples of 32");
+    if (C_logical % 32 || C_logical > C || C_logical <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: logical channels %d not divisible by 32 groups", C_logical);
+    if (C / 8 > 256) GG_FAIL(GG_ERR_UNSUPPORTED, "groupnorm: C > 2048");
+    if (!src1 || (C2 && !src2) || !gamma || !beta || !scale_out || !shift_out || !workspace) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: null pointer");
+    const int nblk = gn_nblk(N, S, C);
+    if ((int64_t)N * nblk * C * 8 > workspace_bytes) GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "groupnorm: workspace %lld < %lld", (long long)workspace_bytes, (long long)N * nblk * C * 8);
+    const long long rpb = (S + nblk - 1) / nblk;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 256 * 16 * sizeof(float), stream, (const bf16_t *)src1, C1,
+                       (const bf16_t *)src2, C2, (long long)S, rpb, (float *)workspace);
+    GG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, stream, (const float *)workspace, nblk, C, C_logical,
+                       (long long)S, gamma, beta, eps, scale_out, shift_out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t *__restrict__ s1, int C1, const bf16_t *__restrict__ s2,
+                                                       int C2, long long S, long long total_pieces,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       int act, bf16_t *__restrict__ out)
+{
+    const int C = C1 + C2;
+    const int P = C >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_pieces;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long row = i / P;                 // row over N*S
+        int piece = (int)(i - row * P);
+        int c0 = piece * 8;
+        int n = (int)(row / S);
+        const bf16_t *src = (c0 >= C1) ? s2 + row * C2 + (c0 - C1) : s1 + row * C1 + c0;
+        bf16x8 v = *reinterpret_cast<const bf16x8 *>(src);
+        const float *sc = scale + (long long)n * C + c0;
+        const float *sh = shift + (long long)n * C + c0;
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(sc), a1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+        f32x4 b0 = *reinterpret_cast<const f32x4 *>(sh), b1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y0 = (float)v[j] * a0[j] + b0[j];
+            float y1 = (float)v[j + 4] * a1[j] + b1[j];
+            if (act) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
+            o[j] = (bf16_t)y0;
+            o[j + 4] = (bf16_t)y1;
+        }
+        *reinterpret_cast<bf16x8 *>(out + row * C + c0) = o;
+    }
+}
+
+extern "C" int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
+                                  const float *scale, const float *shift, int32_t act, void *out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C1 <= 0 || C1 % 32 || C2 % 32 || C2 < 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_apply: C1/C2 must be multiples of 32");
+    if (!src1 || (C2 && !src2) || !scale || !shift || !out) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_apply: null pointer");
+    long long total = (long long)N * S * ((C1 + C2) / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t *)src1, C1,
+                       (const bf16_t *)src2, C2, (long long)S, total, scale, shift, act, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, fp32 two-pass (row cached in registers: C <= 64*8*4 = 2048)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t *__restrict__ x, long long rows, int C,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float eps, bf16_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int P = C >> 3;
+    f32x8 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int piece = lane + 64 * k;
+        if (piece < P) {
+            v[k] = gg_bf16x8_to_f32(*reinterpret_cast<const bf16x8 *>(x + row * C + piece * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[k][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int piece = lane + 64 * k;
+        if (piece < P) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = v[k][j] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int piece = lane + 64 * k;
+        if (piece < P) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int c = piece * 8 + j;
+                o[j] = (bf16_t)((v[k][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *reinterpret_cast<bf16x8 *>(out + row * C + piece * 8) = o;
+        }
+    }
+}
+
+extern "C" int gg_layernorm(const void *x, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,
+                            void *out, void *stream_)
+{
+    if (C % 8 || C > 2048 || C <= 0) GG_FAIL(GG_ERR_UNSUPPORTED, "layernorm: C=%d (need multiple of 8, <= 2048)", C);
+    if (!x || !gamma || !beta || !out) GG_FAIL(GG_ERR_BAD_SHAPE, "layernorm: null pointer");
+    if (rows <= 0) return GG_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)x,
+                       (long long)rows, C, gamma, beta, eps, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16_t *__restrict__ h, long long rows, int inner,
+                                                    bf16_t *__restrict__ out)
+{
+    const int P = inner >> 3;
+    const long long total = rows * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long r = i / P;
+        int c0 = (int)(i - r * P) * 8;
+        bf16x8 a = *reinterpret_cast<const bf16x8 *>(h + r * 2 * inner + c0);
+        bf16x8 g = *reinterpret_cast<const bf16x8 *>(h + r * 2 * inner + inner + c0);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gv = (float)g[j];
+            float ge = 0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f));   // F.gelu, exact erf form
+            o[j] = (bf16_t)((float)a[j] * ge);
+        }
+        *reinterpret_cast<bf16x8 *>(out + r * inner + c0) = o;
+    }
+}
+
+extern "C" int gg_geglu(const void *h, int64_t rows, int32_t inner, void *out, void *stream_)
+{
+    if (inner % 8 || inner <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "geglu: inner %% 8");
+    long long total = (long long)rows * (inner / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) return GG_OK;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)h, (long long)rows,
+                       inner, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t *__restrict__ a, const bf16_t *__restrict__ b, long long n8,
+                                                  bf16_t *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        bf16x8 x = *reinterpret_cast<const bf16x8 *>(a + i * 8);
+        bf16x8 y = *reinterpret_cast<const bf16x8 *>(b + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)x[j] + (float)y[j]);
+        *reinterpret_cast<bf16x8 *>(out + i * 8) = o;
+    }
+}
+
+extern "C" int gg_add(const void *a, const void *b, int64_t n, void *out, void *stream_)
+{
+    if (n % 8) GG_FAIL(GG_ERR_BAD_SHAPE, "add: n %% 8");
+    long long n8 = n / 8;
+    long long blocks = (n8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) return GG_OK;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)a, (const bf16_t *)b,
+                       n8, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}

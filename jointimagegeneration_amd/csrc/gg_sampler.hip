@@ -1,0 +1,423 @@
+// Sampler-side kernels: CCDM fused posterior+sample, DDIM update, layout movers, small fp32 linears.
+#include "gg_common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (counter-based): counter = (voxel lo, voxel hi, draw index, step offset), key = seed.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// CCDM reverse step, one voxel per thread. The arithmetic below is, expression for expression and in the same
+// left-to-right fp32 order (no FMA contraction, IEEE division), the C restatement oracle/ccdm_posterior.c, so the
+// labels agree bit-for-bit when probabilities (not logits) are fed.
+// ------------------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void ccdm_posterior_kernel(const float *__restrict__ head, int head_stride, int is_logits,
+                                                             const int *__restrict__ xt, const float *__restrict__ E,
+                                                             uint64_t seed, const long long *__restrict__ offset_dev, int draw,
+                                                             const float *__restrict__ scalars, int K, long long M,
+                                                             int *__restrict__ labels_out, float *__restrict__ probs_out,
+                                                             bf16_t *__restrict__ onehot_out, int onehot_stride)
+{
+#pragma clang fp contract(off)
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float a = scalars[0], abar = scalars[1];
+    const float Kf = (float)K;
+    const float u = (1.0f - a) / Kf;
+    const float v = (1.0f - abar) / Kf;
+    const float bd = abar * 1.0f + v;
+    const float bo = abar * 0.0f + v;
+    const int x = xt[m];
+
+    float p0[KMAX], A[KMAX], out[KMAX];
+    {
+        const float *hp = head + m * head_stride;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) p0[c] = (c < K) ? hp[c] : 0.f;
+        if (is_logits) {   // nn.Softmax(dim=1) of the UNet head, fp32
+            float mx = p0[0];
+#pragma unroll
+            for (int c = 1; c < KMAX; ++c) if (c < K) mx = fmaxf(mx, p0[c]);
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) if (c < K) { p0[c] = expf(p0[c] - mx); s = s + p0[c]; }
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) if (c < K) p0[c] = p0[c] / s;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        A[c] = a * (c == x ? 1.0f : 0.0f) + u;
+        out[c] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < KMAX; ++d) {
+        if (d < K) {
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) if (c < K) den = den + A[c] * (c == d ? bd : bo);
+            const float pd = p0[d];
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) if (c < K) {
+                const float post = (A[c] * (c == d ? bd : bo)) / den;
+                out[c] = out[c] + post * pd;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) if (c < K) {
+        if (out[c] < 1e-12f) out[c] = 1e-12f;
+        s = s + out[c];
+    }
+    // exponential race
+    float Ev[KMAX];
+    const bool use_race = draw != 0;
+    if (use_race) {
+        if (E) {
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) Ev[c] = (c < K) ? E[m * K + c] : 1.f;
+        } else {
+            const long long off = offset_dev ? offset_dev[0] : 0;
+#pragma unroll
+            for (int q4 = 0; q4 < KMAX / 4; ++q4) {
+                uint32_t ctr[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)q4, (uint32_t)off};
+                philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float uu = (float)((ctr[j] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
+                    Ev[q4 * 4 + j] = -__logf(uu) + 1e-30f;
+                }
+            }
+        }
+    }
+    int best = 0;
+    float bestv = -1.0f;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) if (c < K) {
+        const float pn = out[c] / s;
+        const float r = use_race ? pn / Ev[c] : pn;
+        if (probs_out) probs_out[m * K + c] = pn;
+        if (r > bestv) { bestv = r; best = c; }
+    }
+    labels_out[m] = best;
+    if (onehot_out) {
+        bf16_t *oh = onehot_out + m * onehot_stride;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) if (c < K) oh[c] = (bf16_t)(c == best ? 1.0f : 0.0f);
+    }
+}
+
+extern "C" int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, int32_t head_is_logits, const int32_t *xt,
+                                        const float *E, uint64_t philox_seed, const int64_t *philox_offset_dev, int32_t draw,
+                                        const float *scalars_dev, int32_t K, int64_t M, int32_t *labels_out, float *probs_out,
+                                        void *onehot_out, int32_t onehot_stride, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!head || !xt || !scalars_dev || !labels_out) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: null pointer");
+    if (K < 2 || K > 32) GG_FAIL(GG_ERR_UNSUPPORTED, "ccdm_posterior_sample: K=%d outside [2, 32]", K);
+    if (head_stride < K) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: head_stride < K");
+    if (onehot_out && onehot_stride < K) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: onehot_stride < K");
+    if (M <= 0) return GG_OK;
+    dim3 grid((unsigned)((M + 255) / 256));
+    if (K <= 16)
+        hipLaunchKernelGGL(ccdm_posterior_kernel<16>, grid, dim3(256), 0, stream, head, head_stride, head_is_logits, xt, E,
+                           philox_seed, (const long long *)philox_offset_dev, draw, scalars_dev, K, (long long)M, labels_out,
+                           probs_out, (bf16_t *)onehot_out, onehot_stride);
+    else
+        hipLaunchKernelGGL(ccdm_posterior_kernel<32>, grid, dim3(256), 0, stream, head, head_stride, head_is_logits, xt, E,
+                           philox_seed, (const long long *)philox_offset_dev, draw, scalars_dev, K, (long long)M, labels_out,
+                           probs_out, (bf16_t *)onehot_out, onehot_stride);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+__global__ __launch_bounds__(256) void labels_to_onehot_kernel(const int *__restrict__ labels, long long M, int K,
+                                                               bf16_t *__restrict__ out, int stride)
+{
+    // one thread per (voxel, 8-channel piece): writes the full padded row (zeros beyond K)
+    const int P = stride >> 3;
+    const long long total = M * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long m = i / P;
+        int c0 = (int)(i - m * P) * 8;
+        int lab = labels[m];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((c0 + j == lab && c0 + j < K) ? 1.0f : 0.0f);
+        *reinterpret_cast<bf16x8 *>(out + m * stride + c0) = o;
+    }
+}
+
+extern "C" int gg_labels_to_onehot(const int32_t *labels, int64_t M, int32_t K, void *onehot_out, int32_t stride, void *stream_)
+{
+    if (!labels || !onehot_out) GG_FAIL(GG_ERR_BAD_SHAPE, "labels_to_onehot: null pointer");
+    if (stride % 8 || stride < K) GG_FAIL(GG_ERR_BAD_SHAPE, "labels_to_onehot: stride %d (K=%d)", stride, K);
+    if (M <= 0) return GG_OK;
+    long long total = (long long)M * (stride / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(labels_to_onehot_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, labels, (long long)M, K,
+                       (bf16_t *)onehot_out, stride);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// DDIM update (ddim.py:190-204), fp32; same expression order as oracle/samplers.py:ddim_step.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddim_step_kernel(float *__restrict__ x, const float *__restrict__ eps, int eps_stride,
+                                                        const float *__restrict__ noise, const float *__restrict__ sc,
+                                                        long long M, int C, float *__restrict__ pred_x0_out,
+                                                        bf16_t *__restrict__ unet_in, int unet_in_stride)
+{
+#pragma clang fp contract(off)
+    const float a_t = sc[0], a_prev = sc[1], sigma = sc[2], s1m = sc[3];
+    const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dirc = sqrtf(1.0f - a_prev - sigma * sigma);
+    const long long total = M * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long m = i / C;
+        int c = (int)(i - m * C);
+        float e = eps[m * eps_stride + c];
+        float xv = x[i];
+        float px0 = (xv - s1m * e) / sqrt_at;
+        float xn = sqrt_ap * px0 + dirc * e;
+        if (noise) xn = xn + sigma * noise[i];
+        x[i] = xn;
+        if (pred_x0_out) pred_x0_out[i] = px0;
+        if (unet_in) unet_in[m * unet_in_stride + c] = (bf16_t)xn;
+    }
+}
+
+extern "C" int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev,
+                            int64_t M, int32_t C, float *pred_x0_out, void *unet_in, int32_t unet_in_stride, void *stream_)
+{
+    if (!x || !eps || !scalars_dev) GG_FAIL(GG_ERR_BAD_SHAPE, "ddim_step: null pointer");
+    if (eps_stride < C || (unet_in && unet_in_stride < C)) GG_FAIL(GG_ERR_BAD_SHAPE, "ddim_step: stride < C");
+    long long total = (long long)M * C;
+    if (total <= 0) return GG_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, eps, eps_stride, noise,
+                       scalars_dev, (long long)M, C, pred_x0_out, (bf16_t *)unet_in, unet_in_stride);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// min-max normalisation over a whole tensor (ordered-uint atomics; deterministic)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+
+__global__ void minmax_init_kernel(uint32_t *ws) { ws[0] = 0xFFFFFFFFu; ws[1] = 0u; }
+
+__global__ __launch_bounds__(256) void minmax_reduce_kernel(const float *__restrict__ src, long long n, uint32_t *ws)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = src[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&ws[0], f2ord(mn)); atomicMax(&ws[1], f2ord(mx)); }
+}
+
+__global__ __launch_bounds__(256) void minmax_apply_kernel(const float *__restrict__ src, long long n, const uint32_t *ws,
+                                                           float *__restrict__ dst)
+{
+#pragma clang fp contract(off)
+    const float mn = ord2f(ws[0]), mx = ord2f(ws[1]);
+    const float den = mx - mn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (src[i] - mn) / den;
+}
+
+extern "C" int gg_minmax_normalise(const float *src, int64_t n, float *dst, float *workspace2, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst || !workspace2) GG_FAIL(GG_ERR_BAD_SHAPE, "minmax_normalise: null pointer");
+    if (n <= 0) return GG_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, stream, (uint32_t *)workspace2);
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (long long)n, (uint32_t *)workspace2);
+    hipLaunchKernelGGL(minmax_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (long long)n, (const uint32_t *)workspace2, dst);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layout movers
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float *__restrict__ src, int N, int C, long long S,
+                                                         bf16_t *__restrict__ dst, int C_pad, int c_off, int zero_fill)
+{
+    // thread per (n, s, 8-channel piece of the padded row)
+    const int P = C_pad >> 3;
+    const long long total = (long long)N * S * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // order: piece slowest within (n), s fastest -> coalesced fp32 reads along s
+        long long ns = i % ((long long)N * S);
+        int piece = (int)(i / ((long long)N * S));
+        long long n = ns / S, s = ns - n * S;
+        int c0 = piece * 8;
+        bool any = false;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c0 + j - c_off;
+            float v = 0.f;
+            if (c >= 0 && c < C) { v = src[(n * C + c) * S + s]; any = true; }
+            o[j] = (bf16_t)v;
+        }
+        bf16_t *d = dst + (n * S + s) * C_pad + c0;
+        if (zero_fill) {
+            *reinterpret_cast<bf16x8 *>(d) = o;
+        } else if (any) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int c = c0 + j - c_off;
+                if (c >= 0 && c < C) d[j] = o[j];
+            }
+        }
+    }
+}
+
+extern "C" int gg_nchw_f32_to_cl_bf16(const float *src, int32_t N, int32_t C, int64_t S, void *dst, int32_t C_pad,
+                                      int32_t c_offset, int32_t zero_fill, void *stream_)
+{
+    if (!src || !dst) GG_FAIL(GG_ERR_BAD_SHAPE, "nchw_to_cl: null pointer");
+    if (C_pad % 8 || c_offset < 0 || c_offset + C > C_pad) GG_FAIL(GG_ERR_BAD_SHAPE, "nchw_to_cl: C=%d offset=%d C_pad=%d", C, c_offset, C_pad);
+    long long total = (long long)N * S * (C_pad / 8);
+    if (total <= 0) return GG_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nchw_to_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, src, N, C, (long long)S,
+                       (bf16_t *)dst, C_pad, c_offset, zero_fill);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_nchw_kernel(const T *__restrict__ src, int N, int C, long long S, int C_pad,
+                                                         float *__restrict__ dst)
+{
+    const long long total = (long long)N * C * S;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long s = i % S;
+        long long nc = i / S;
+        int c = (int)(nc % C);
+        long long n = nc / C;
+        dst[i] = (float)src[(n * S + s) * C_pad + c];
+    }
+}
+
+extern "C" int gg_cl_to_nchw_f32(const void *src, int32_t src_dtype, int32_t N, int32_t C, int64_t S, int32_t C_pad, float *dst,
+                                 void *stream_)
+{
+    if (!src || !dst) GG_FAIL(GG_ERR_BAD_SHAPE, "cl_to_nchw: null pointer");
+    if (C > C_pad) GG_FAIL(GG_ERR_BAD_SHAPE, "cl_to_nchw: C > C_pad");
+    long long total = (long long)N * C * S;
+    if (total <= 0) return GG_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (src_dtype == GG_BF16)
+        hipLaunchKernelGGL(cl_to_nchw_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t *)src, N, C,
+                           (long long)S, C_pad, dst);
+    else if (src_dtype == GG_F32)
+        hipLaunchKernelGGL(cl_to_nchw_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (const float *)src, N, C,
+                           (long long)S, C_pad, dst);
+    else
+        GG_FAIL(GG_ERR_BAD_DTYPE, "cl_to_nchw: dtype");
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small fp32 linear (one wave per output element) and sinusoidal embedding
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict__ in, int M, int I, const float *__restrict__ W,
+                                                         const float *__restrict__ b, int O, int act_in, float *__restrict__ out,
+                                                         long long out_stride)
+{
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= (long long)M * O) return;
+    const int m = (int)(w / O), o = (int)(w - (long long)m * O);
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        float v = in[(long long)m * I + i];
+        if (act_in) v = v / (1.0f + expf(-v));
+        acc += v * W[(long long)o * I + i];
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) out[(long long)m * out_stride + o] = acc + (b ? b[o] : 0.f);
+}
+
+extern "C" int gg_linear_f32(const float *in, int32_t M, int32_t I, const float *W, const float *b, int32_t O, int32_t act_in,
+                             float *out, int64_t out_stride, void *stream_)
+{
+    if (!in || !W || !out) GG_FAIL(GG_ERR_BAD_SHAPE, "linear_f32: null pointer");
+    if (M <= 0 || I <= 0 || O <= 0 || out_stride < O) GG_FAIL(GG_ERR_BAD_SHAPE, "linear_f32: bad shape");
+    long long waves = (long long)M * O;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, in, M, I, W, b, O, act_in,
+                       out, (long long)out_stride);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+__global__ void timestep_embedding_kernel(const float *__restrict__ t, int M, int dim, float max_period, float *__restrict__ out)
+{
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * dim) return;
+    const int m = i / dim, j = i - m * dim;
+    float v = 0.f;
+    if (j < 2 * half) {
+        int f = (j < half) ? j : j - half;
+        float freq = expf(-logf(max_period) * (float)f / (float)half);
+        float arg = t[m] * freq;
+        v = (j < half) ? cosf(arg) : sinf(arg);
+    }
+    out[i] = v;
+}
+
+extern "C" int gg_timestep_embedding(const float *t, int32_t M, int32_t dim, float max_period, float *out, void *stream_)
+{
+    if (!t || !out || M <= 0 || dim <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "timestep_embedding: bad args");
+    int total = M * dim;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, t, M, dim, max_period, out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void gg_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *gg_last_error(void) { return g_err; }
+extern "C" int gg_version(void) { return 100; }

@@ -1,0 +1,292 @@
+"""Torch-facing wrappers over the C-ABI.  PyTorch only supplies device memory and the stream (plumbing);
+every arithmetic op below is one or more hand-written HIP kernels in libguidegen_hip.so.
+
+Activations travel as `CL` = channels-last bf16 tensors [N, D, H, W, Cpad] (D == 1 for 2-D), Cpad a multiple of 32
+with zero pad lanes, plus the logical channel count.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GG_BF16, GG_F32, AttentionDesc, ConvDesc, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the GuideGen engine runs on MI355X only "
+                           "(no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+@dataclass
+class CL:
+    """Channels-last activation: t is [N, D, H, W, Cpad] (bf16, or fp32 for head outputs); C = logical channels."""
+    t: torch.Tensor
+    C: int
+
+    @property
+    def N(self): return self.t.shape[0]
+    @property
+    def spatial(self) -> Tuple[int, int, int]: return tuple(self.t.shape[1:4])
+    @property
+    def S(self) -> int: return self.t.shape[1] * self.t.shape[2] * self.t.shape[3]
+    @property
+    def Cpad(self) -> int: return self.t.shape[4]
+
+
+# ----------------------------------------------------------------------------------------------- layout movers
+def to_cl(x: torch.Tensor, c_pad: Optional[int] = None, out: Optional[torch.Tensor] = None, c_offset: int = 0,
+          zero_fill: bool = True) -> CL:
+    """NC[D]HW fp32 -> CL bf16 (optionally into channels [c_offset, c_offset+C) of an existing buffer)."""
+    require_gpu(x, "to_cl")
+    lib = _lib.load()
+    x = x.contiguous().float()
+    N, Cc = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    sp3 = (1,) * (3 - len(sp)) + sp
+    S = sp3[0] * sp3[1] * sp3[2]
+    if out is None:
+        cp = c_pad or pad32(Cc + c_offset)
+        out = torch.empty((N,) + sp3 + (cp,), dtype=torch.bfloat16, device=x.device)
+    cp = out.shape[-1]
+    check(lib.gg_nchw_f32_to_cl_bf16(x.data_ptr(), N, Cc, S, out.data_ptr(), cp, c_offset, 1 if zero_fill else 0, _stream()),
+          "gg_nchw_f32_to_cl_bf16")
+    return CL(out, Cc + c_offset)
+
+
+def from_cl(cl: CL, ndim_spatial: int) -> torch.Tensor:
+    """CL (bf16 or fp32) -> NC[D]HW fp32."""
+    lib = _lib.load()
+    t = cl.t
+    N, D, H, W, cp = t.shape
+    sp = (D, H, W)[3 - ndim_spatial:]
+    out = torch.empty((N, cl.C) + sp, dtype=torch.float32, device=t.device)
+    dt = GG_BF16 if t.dtype == torch.bfloat16 else GG_F32
+    check(lib.gg_cl_to_nchw_f32(t.data_ptr(), dt, N, cl.C, D * H * W, cp, out.data_ptr(), _stream()), "gg_cl_to_nchw_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- conv
+def pack_conv_weight(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """fp32 OI[D]HW / OI (linear) -> MFMA tile order bf16 (device)."""
+    require_gpu(w, "pack_conv_weight")
+    lib = _lib.load()
+    w = w.detach().contiguous().float()
+    Cout, Cin = w.shape[:2]
+    ntaps = 1
+    for s in w.shape[2:]:
+        ntaps *= s
+    nbytes = lib.gg_conv_packed_weight_bytes(Cout, cin_pad, ntaps)
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    check(lib.gg_conv_pack_weight(w.data_ptr(), Cout, Cin, cin_pad, ntaps, out.data_ptr(), _stream()), "gg_conv_pack_weight")
+    return out
+
+
+def pad_bias(b: Optional[torch.Tensor], cout: int, device) -> torch.Tensor:
+    out = torch.zeros(pad32(cout), dtype=torch.float32, device=device)
+    if b is not None:
+        out[:cout] = b.detach().float()
+    return out
+
+
+def conv_out_extent(in_sp: Sequence[int], k: Sequence[int], stride: int, pad: int, upsample: bool):
+    out = []
+    for s, kk in zip(in_sp, k):
+        if kk == 1:
+            out.append((s - 1) // stride + 1)
+        else:
+            e = s * 2 if upsample else s
+            if stride == 1:
+                out.append(e + 2 * pad - 2)
+            else:
+                out.append((e + 2 - 3) // 2 + 1 if pad == 1 else (e + 1 - 3) // 2 + 1)
+    return tuple(out)
+
+
+def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
+         upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
+         bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+         out: Optional[torch.Tensor] = None) -> CL:
+    lib = _lib.load()
+    t1 = src1.t
+    N, D, H, W, C1 = t1.shape
+    Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
+    cp = pad32(cout)
+    if out is None:
+        out = torch.empty((N, Do, Ho, Wo, cp), dtype=torch.float32 if out_f32 else torch.bfloat16, device=t1.device)
+    d = ConvDesc()
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = C1, (src2.t.shape[-1] if src2 is not None else 0)
+    d.Cout, d.Cout_pad = cout, cp
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.out_dtype = GG_F32 if out.dtype == torch.float32 else GG_BF16
+    d.prologue_act = 1 if prologue is not None else 0
+    d.src1 = t1.data_ptr()
+    d.src2 = _ptr(src2.t) if src2 is not None else None
+    d.weight = weight.data_ptr()
+    d.bias = _ptr(bias)
+    d.bias_stride = cp if bias_per_sample else 0
+    d.residual = _ptr(residual.t) if residual is not None else None
+    d.out = out.data_ptr()
+    d.gn_scale = _ptr(prologue[0]) if prologue is not None else None
+    d.gn_shift = _ptr(prologue[1]) if prologue is not None else None
+    check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
+    return CL(out, cout)
+
+
+# ----------------------------------------------------------------------------------------------- norms / elementwise
+def groupnorm_stats(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, src2: Optional[CL] = None):
+    """Returns per-(n, c) fp32 (scale, shift) with y = x*scale + shift == GroupNorm(32, C)(x)."""
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    if src2 is not None and src1.C != C1:
+        raise RuntimeError("two-source GroupNorm needs an unpadded first source")
+    Ct = C1 + C2
+    ws_bytes = lib.gg_groupnorm_workspace_bytes(N, S, Ct)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=src1.t.device)
+    scale = torch.empty((N, Ct), dtype=torch.float32, device=src1.t.device)
+    shift = torch.empty_like(scale)
+    check(lib.gg_groupnorm_stats(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, c_log,
+                                 gamma.data_ptr(), beta.data_ptr(), eps, scale.data_ptr(), shift.data_ptr(), ws.data_ptr(),
+                                 ws_bytes, _stream()), "gg_groupnorm_stats")
+    return scale, shift
+
+
+def groupnorm_apply(src1: CL, scale: torch.Tensor, shift: torch.Tensor, act: bool, src2: Optional[CL] = None) -> CL:
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    out = torch.empty(tuple(src1.t.shape[:4]) + (C1 + C2,), dtype=torch.bfloat16, device=src1.t.device)
+    check(lib.gg_groupnorm_apply(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, scale.data_ptr(),
+                                 shift.data_ptr(), 1 if act else 0, out.data_ptr(), _stream()), "gg_groupnorm_apply")
+    return CL(out, src1.C + (src2.C if src2 is not None else 0))
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty_like(x)
+    check(lib.gg_layernorm(x.data_ptr(), rows, Cc, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), _stream()), "gg_layernorm")
+    return out
+
+
+def geglu(h: torch.Tensor, inner: int) -> torch.Tensor:
+    lib = _lib.load()
+    rows = h.numel() // (2 * inner)
+    out = torch.empty(tuple(h.shape[:-1]) + (inner,), dtype=torch.bfloat16, device=h.device)
+    check(lib.gg_geglu(h.data_ptr(), rows, inner, out.data_ptr(), _stream()), "gg_geglu")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    check(lib.gg_add(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), "gg_add")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, N: int, heads: int, head_dim: int, Tq: int,
+              Tkv: int, ld_hs_q, ld_hs_k, ld_hs_v, ld_hs_o, scale: float, q_off=0, k_off=0, v_off=0) -> None:
+    """q/k/v/out are bf16 tensors; element (n,t,h,d) at base + off + (n*T+t)*ld + h*hs + d."""
+    lib = _lib.load()
+    d = AttentionDesc()
+    d.N, d.heads, d.head_dim, d.Tq, d.Tkv = N, heads, head_dim, Tq, Tkv
+    d.ldq, d.hsq = ld_hs_q
+    d.ldk, d.hsk = ld_hs_k
+    d.ldv, d.hsv = ld_hs_v
+    d.ldo, d.hso = ld_hs_o
+    d.scale = scale
+    d.q = q.data_ptr() + 2 * q_off
+    d.k = k.data_ptr() + 2 * k_off
+    d.v = v.data_ptr() + 2 * v_off
+    d.out = out.data_ptr()
+    check(lib.gg_attention_forward(C.byref(d), _stream()), "gg_attention_forward")
+
+
+# ----------------------------------------------------------------------------------------------- small fp32 ops
+def linear_f32(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], act_in: bool = False,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous()
+    M, I = x.shape
+    O = W.shape[0]
+    if out is None:
+        out = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    check(lib.gg_linear_f32(x.data_ptr(), M, I, W.data_ptr(), _ptr(b), O, 1 if act_in else 0, out.data_ptr(), out.stride(0), _stream()),
+          "gg_linear_f32")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    lib = _lib.load()
+    t = t.float().contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(lib.gg_timestep_embedding(t.data_ptr(), t.shape[0], dim, max_period, out.data_ptr(), _stream()), "gg_timestep_embedding")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- samplers
+def ccdm_posterior_sample(head: torch.Tensor, head_is_logits: bool, xt: torch.Tensor, scalars: torch.Tensor, K: int, *,
+                          E: Optional[torch.Tensor] = None, philox_seed: int = 0, philox_offset: Optional[torch.Tensor] = None,
+                          draw: bool = True, labels_out: Optional[torch.Tensor] = None, probs_out: Optional[torch.Tensor] = None,
+                          onehot_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """head: fp32 [..., stride] (probs or logits, channels-last); xt int32 [M]; scalars fp32[2] on device."""
+    lib = _lib.load()
+    stride = head.shape[-1]
+    M = head.numel() // stride
+    if labels_out is None:
+        labels_out = torch.empty(M, dtype=torch.int32, device=head.device)
+    check(lib.gg_ccdm_posterior_sample(head.data_ptr(), stride, 1 if head_is_logits else 0, xt.data_ptr(), _ptr(E), philox_seed,
+                                       _ptr(philox_offset), 1 if draw else 0, scalars.data_ptr(), K, M, labels_out.data_ptr(),
+                                       _ptr(probs_out), _ptr(onehot_out), onehot_out.shape[-1] if onehot_out is not None else 0,
+                                       _stream()), "gg_ccdm_posterior_sample")
+    return labels_out
+
+
+def labels_to_onehot(labels: torch.Tensor, K: int, out: torch.Tensor) -> None:
+    lib = _lib.load()
+    check(lib.gg_labels_to_onehot(labels.data_ptr(), labels.numel(), K, out.data_ptr(), out.shape[-1], _stream()), "gg_labels_to_onehot")
+
+
+def ddim_step(x: torch.Tensor, eps: torch.Tensor, scalars: torch.Tensor, noise: Optional[torch.Tensor] = None,
+              pred_x0_out: Optional[torch.Tensor] = None, unet_in: Optional[torch.Tensor] = None) -> None:
+    """x fp32 CL [M, C] (updated in place); eps fp32 CL [M, stride]; scalars fp32[4] on device."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    check(lib.gg_ddim_step(x.data_ptr(), eps.data_ptr(), eps.shape[-1], _ptr(noise), scalars.data_ptr(), M, Cc, _ptr(pred_x0_out),
+                           _ptr(unet_in), unet_in.shape[-1] if unet_in is not None else 0, _stream()), "gg_ddim_step")
+
+
+def minmax_normalise(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(src)
+    ws = torch.empty(2, dtype=torch.float32, device=src.device)
+    check(lib.gg_minmax_normalise(src.data_ptr(), src.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "gg_minmax_normalise")
+    return out
