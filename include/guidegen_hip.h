@@ -73,6 +73,8 @@ typedef struct {
     void *out;                 /* CL [N,Do,Ho,Wo,Cout_pad]                                              */
     const float *gn_scale;     /* fp32 [N, C1+C2] or NULL (see prologue_act)                             */
     const float *gn_shift;
+    void *workspace;           /* caller-owned scratch (split-K slabs); size from gg_conv_workspace_bytes */
+    int64_t workspace_bytes;
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -82,6 +84,8 @@ int64_t gg_conv_packed_weight_bytes(int32_t Cout, int32_t Cin_pad, int32_t ntaps
  * `w_f32` is a device pointer, logical shape [Cout, Cin, ntaps]; cin_map (host, may be NULL) is not used. */
 int gg_conv_pack_weight(const float *w_f32, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t ntaps,
                         void *packed_bf16, void *stream);
+/* Scratch bytes gg_conv_forward needs for this shape (0 for most; > 0 when the under-filled grid is split over K). */
+int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -175,6 +179,14 @@ int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, const float *no
 /* Slice normalisation (ds - min)/(max - min) over the whole tensor (latentdiffusion/sample_diffusion.py:222).
  * workspace: >= 2 floats, zero-initialised by the call. */
 int gg_minmax_normalise(const float *src, int64_t n, float *dst, float *workspace2, void *stream);
+
+/* Stage glue: CCDM labels -> LDM conditioning slice on the device: nearest upsample of the
+ * label volume [N,Dm,Hm,Wm] to (D,H,W), torch.rot90(k=3) on (H,W), value label/255 in channel 1, previous generated
+ * slice `prev` fp32 [N,H,W] (or NULL = zeros) in channel 0, remaining lanes of the bf16 CL row zeroed
+ * (latentdiffusion/sample_diffusion.py:199-210). mask_out (optional) receives the fp32 mask slice. */
+int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t Dm, int32_t Hm, int32_t Wm, int32_t slice, int32_t D,
+                          int32_t H, int32_t W, const float *prev, void *cond_cl, int32_t stride, float *mask_out,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,8 @@ struct ConvParams {
     const bf16_t *src1, *src2, *weight, *residual;
     const float *bias, *gn_scale, *gn_shift;
     void *out;
+    float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
+    int splitk;
 };
 
 // 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = l&15, chunk = l>>4):
@@ -75,7 +77,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     u32x4 xreg[2];
     u32x4 wreg[WITER];
 
-    int chunk = 0, tkd = 0, tkh = 0, tkw = 0, tap = 0;  // k-step counters for the NEXT global load
+    // split-K: blockIdx.z owns k-steps [ks_begin, ks_end) of the (chunk outer, tap inner) sequence
+    const int KS_all = p.ntaps * p.nchunk;
+    const int ks_begin = (int)(((long long)KS_all * blockIdx.z) / p.splitk);
+    const int ks_end = (int)(((long long)KS_all * (blockIdx.z + 1)) / p.splitk);
+    int chunk = ks_begin / p.ntaps, tap = ks_begin - (ks_begin / p.ntaps) * p.ntaps;   // counters for the NEXT global load
+    int tkd = tap / (p.kh * p.kw), tkh = (tap / p.kw) % p.kh, tkw = tap % p.kw;
 
     auto load_regs = [&]() {
         const bool second = chunk >= p.nchunk1;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         }
     };
 
-    const int KS = p.ntaps * p.nchunk;
+    const int KS = ks_end - ks_begin;
     load_regs();
     write_lds(0);
     __syncthreads();
@@ -185,6 +192,19 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         __syncthreads();
     }
 
+    if (p.splitk > 1) {   // raw fp32 partial tile -> slab; bias/residual/cast happen in conv_splitk_reduce_kernel
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            long long m = m0 + wave * 32 + pt * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ct = 0; ct < 2 * NT; ++ct) {
+                int co = (g0 * 32) + ct * 16 + fq * 4;
+                *reinterpret_cast<f32x4 *>(p.ws + ((long long)blockIdx.z * p.M + m) * p.Cout_pad + co) = acc[pt][ct];
+            }
+        }
+        return;
+    }
     // ---- epilogue: + bias[n] (+ residual) -> bf16 / fp32, 4 consecutive channels per lane
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -217,6 +237,42 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
                 for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
                 *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ split-K reduce
+// out[m, co] = sum_z slab[z][m][co] (fixed order: deterministic) + bias[n][co] (+ residual) -> bf16 / fp32
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p)
+{
+    const int q4 = p.Cout_pad >> 2;
+    const long long total = p.M * q4;
+    const long long osp = (long long)p.Do * p.Ho * p.Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long m = i / q4;
+        int co = (int)(i - m * q4) * 4;
+        long long o = m * p.Cout_pad + co;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(p.ws + o);
+        for (int z = 1; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(p.ws + (long long)z * p.M * p.Cout_pad + o);
+        if (p.bias) {
+            int n = (int)(m / osp);
+            v += *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co);
+        }
+        if (p.residual) {
+            bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (co + j >= p.Cout) v[j] = 0.f;
+        if (p.out_dtype == GG_F32) {
+            *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+        } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
         }
     }
 }
@@ -269,10 +325,49 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream);
 template <int NT>
 static int launch_gather(const ConvParams &p, hipStream_t stream)
 {
-    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.Cout_pad / (32 * NT)));
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.Cout_pad / (32 * NT)), (unsigned)p.splitk);
     hipLaunchKernelGGL(conv_gather_kernel<NT>, grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
+    if (p.splitk > 1) {
+        long long total = p.M * (p.Cout_pad / 4);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        GG_CHECK_LAUNCH();
+    }
     return GG_OK;
+}
+
+// Tile/split plan of the gather kernel. Large grids: widest cout tile (NT in {4,5,3,2,1}) and no split. Under-filled
+// grids (small M: deep UNet levels at batch 1) are weight-streaming/latency bound: shrink the cout tile and split K
+// over blockIdx.z until ~2 blocks per CU exist, keeping >= 8 k-steps per block.
+struct GatherPlan { int NT, splitk; };
+static GatherPlan plan_gather(long long M, int Cout_pad, int KS)
+{
+    const int G = Cout_pad / 32;
+    int NT = (G % 4 == 0) ? 4 : (G % 5 == 0) ? 5 : (G % 3 == 0) ? 3 : (G % 2 == 0) ? 2 : 1;
+    const long long mb = (M + 127) / 128;
+    int splitk = 1;
+    if (mb * (G / NT) < 192) {
+        if (G % 2 == 0 && NT > 2 && mb * (G / 2) <= 1024) NT = 2;
+        if (mb * (G / NT) < 192 && NT > 1) NT = 1;
+        long long blocks = mb * (G / NT);
+        long long want = (512 + blocks - 1) / blocks;
+        long long maxs = KS / 8 > 0 ? KS / 8 : 1;
+        splitk = (int)(want < maxs ? want : maxs);
+        if (splitk < 1) splitk = 1;
+        if (splitk > 64) splitk = 64;
+    }
+    return {NT, splitk};
+}
+
+extern "C" int64_t gg_conv_workspace_bytes(const gg_conv_desc *d)
+{
+    if (!d) return 0;
+    long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
+    int KS = d->kd * d->kh * d->kw * ((d->C1 + d->C2) / 32);
+    GatherPlan pl = plan_gather(M, d->Cout_pad, KS);
+    return pl.splitk > 1 ? (int64_t)pl.splitk * M * d->Cout_pad * 4 : 0;
 }
 
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
@@ -311,14 +406,25 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
     p.src1 = (const bf16_t *)d->src1; p.src2 = (const bf16_t *)d->src2; p.weight = (const bf16_t *)d->weight;
     p.residual = (const bf16_t *)d->residual; p.bias = d->bias; p.gn_scale = d->gn_scale; p.gn_shift = d->gn_shift;
     p.out = d->out;
+    p.ws = nullptr;
+    p.splitk = 1;
 
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;
 
-    const int G = p.Cout_pad / 32;
-    if (G % 4 == 0) return launch_gather<4>(p, stream);
-    if (G % 5 == 0) return launch_gather<5>(p, stream);
-    if (G % 3 == 0) return launch_gather<3>(p, stream);
-    if (G % 2 == 0) return launch_gather<2>(p, stream);
-    return launch_gather<1>(p, stream);
+    GatherPlan pl = plan_gather(p.M, p.Cout_pad, p.ntaps * p.nchunk);
+    if (pl.splitk > 1) {
+        const long long need = (long long)pl.splitk * p.M * p.Cout_pad * 4;
+        if (!d->workspace || d->workspace_bytes < need)
+            GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "conv: split-K needs %lld workspace bytes (gg_conv_workspace_bytes), got %lld", need, (long long)d->workspace_bytes);
+        p.ws = (float *)d->workspace;
+        p.splitk = pl.splitk;
+    }
+    switch (pl.NT) {
+        case 5: return launch_gather<5>(p, stream);
+        case 4: return launch_gather<4>(p, stream);
+        case 3: return launch_gather<3>(p, stream);
+        case 2: return launch_gather<2>(p, stream);
+        default: return launch_gather<1>(p, stream);
+    }
 }

@@ -62,53 +62,46 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t *__restric
     }
 }
 
-// Stage 2: one block per (n): combine partials in fp64 (fixed order), per-group mean/rstd, fold gamma/beta into
-// per-(n,c) scale/shift:  y = x*scale + shift  with scale = rstd*gamma, shift = beta - mean*rstd*gamma.
+// Stage 2: one block per (n, group): combine the block partials of the group's channels in fp64 with a fixed
+// reduction tree (deterministic), then fold gamma/beta into per-(n,c) scale/shift:
+//   y = x*scale + shift,  scale = rstd*gamma,  shift = beta - mean*rstd*gamma.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part, int nblk, int C, int C_logical,
                                                           long long S, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
                                                           float *__restrict__ scale, float *__restrict__ shift)
 {
-    const int n = blockIdx.x;
+    const int n = blockIdx.y, g = blockIdx.x;
     const int cpg = C_logical / 32;
-    __shared__ double csum[2048], csq[2048];
-    __shared__ float gmean[32], grstd[32];
-    // each thread owns channels c = tid, tid+256, ...: fixed-order fp64 combine of the block partials
-    for (int c = threadIdx.x; c < C_logical; c += blockDim.x) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            const float *q = part + (((long long)n * nblk + k) * C + c) * 2;
-            a += (double)q[0];
-            b += (double)q[1];
-        }
-        csum[c] = a;
-        csq[c] = b;
+    const int tid = threadIdx.x;
+    __shared__ double ra[256], rb[256];
+    double a = 0.0, b = 0.0;
+    const int total = nblk * cpg;
+    for (int i = tid; i < total; i += 256) {
+        const int k = i / cpg, j = i - k * cpg;
+        const float *q = part + (((long long)n * nblk + k) * C + g * cpg + j) * 2;
+        a += (double)q[0];
+        b += (double)q[1];
     }
+    ra[tid] = a;
+    rb[tid] = b;
     __syncthreads();
-    if (threadIdx.x < 32) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < cpg; ++j) {
-            a += csum[threadIdx.x * cpg + j];
-            b += csq[threadIdx.x * cpg + j];
-        }
-        double cnt = (double)S * cpg;
-        double mean = a / cnt;
-        double var = b / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gmean[threadIdx.x] = (float)mean;
-        grstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { ra[tid] += ra[tid + s]; rb[tid] += rb[tid + s]; }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float sc = 0.f, sh = 0.f;
-        if (c < C_logical) {
-            int g = c / cpg;
-            sc = grstd[g] * gamma[c];
-            sh = beta[c] - gmean[g] * sc;
-        }
+    const double cnt = (double)S * cpg;
+    const double mean = ra[0] / cnt;
+    double var = rb[0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const float sc = frstd * gamma[c];
         scale[(long long)n * C + c] = sc;
-        shift[(long long)n * C + c] = sh;
+        shift[(long long)n * C + c] = beta[c] - fmean * sc;
     }
+    if (g == 0)   // zero the pad lanes once
+        for (int c = C_logical + tid; c < C; c += 256) { scale[(long long)n * C + c] = 0.f; shift[(long long)n * C + c] = 0.f; }
 }
 
 extern "C" int64_t gg_groupnorm_workspace_bytes(int32_t N, int64_t S, int32_t C)
@@ -145,7 +138,7 @@ extern "C" int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 256 * 16 * sizeof(float), stream, (const bf16_t *)src1, C1,
                        (const bf16_t *)src2, C2, (long long)S, rpb, (float *)workspace);
     GG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, stream, (const float *)workspace, nblk, C, C_logical,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, N), dim3(256), 0, stream, (const float *)workspace, nblk, C, C_logical,
                        (long long)S, gamma, beta, eps, scale_out, shift_out);
     GG_CHECK_LAUNCH();
     return GG_OK;

@@ -265,6 +265,54 @@ extern "C" int gg_minmax_normalise(const float *src, int64_t n, float *dst, floa
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Stage glue: CCDM label volume -> conditioning slice of the LDM loop, on the device.
+//   up[d,y,x]  = labels[n, floor(d*Dm/D), floor(y*Hm/H), floor(x*Wm/W)]      nearest (order-0) upsample
+//   rot[i,j]   = up[slice, H-1-j, i]                                          torch.rot90(k=3) on (H, W)
+//   cond[n,i,j,0] = prev[n,i,j] (previous generated slice, [0,1]) ; cond[n,i,j,1] = rot[i,j]/255 ; other lanes 0
+// (latentdiffusion/sample_diffusion.py:199-210; value convention ldm/data/ruijin_pimage_and_mask.py:127-131)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_to_cond_slice_kernel(const int *__restrict__ labels, int N, int Dm, int Hm, int Wm,
+                                                                 int slice, int D, int H, int W, const float *__restrict__ prev,
+                                                                 bf16_t *__restrict__ cond, int stride, float *__restrict__ mask_out)
+{
+    const long long total = (long long)N * H * W;
+    const int sd = (int)(((long long)slice * Dm) / D);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        int j = (int)(t % W);
+        int i = (int)((t / W) % H);
+        int n = (int)(t / ((long long)W * H));
+        int y = H - 1 - j, x = i;                         // rot90(k=3): out[i][j] = up[H-1-j][i]  (H == W)
+        int sy = (int)(((long long)y * Hm) / H), sx = (int)(((long long)x * Wm) / W);
+        int lab = labels[(((long long)n * Dm + sd) * Hm + sy) * Wm + sx];
+        float mv = (float)lab / 255.0f;
+        float pv = prev ? prev[t] : 0.f;
+        bf16_t *row = cond + t * stride;
+        bf16x8 o = {(bf16_t)pv, (bf16_t)mv, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        *reinterpret_cast<bf16x8 *>(row) = o;
+        bf16x8 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        for (int c = 8; c < stride; c += 8) *reinterpret_cast<bf16x8 *>(row + c) = z;
+        if (mask_out) mask_out[t] = mv;
+    }
+}
+
+extern "C" int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t Dm, int32_t Hm, int32_t Wm, int32_t slice, int32_t D,
+                                     int32_t H, int32_t W, const float *prev, void *cond_cl, int32_t stride, float *mask_out,
+                                     void *stream_)
+{
+    if (!labels || !cond_cl) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: null pointer");
+    if (H != W) GG_FAIL(GG_ERR_UNSUPPORTED, "mask_to_cond_slice: rot90 needs H == W");
+    if (stride % 8 || stride < 8) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: stride");
+    if (slice < 0 || slice >= D) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: slice %d outside [0,%d)", slice, D);
+    long long total = (long long)N * H * W;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mask_to_cond_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, labels, N, Dm, Hm, Wm, slice,
+                       D, H, W, prev, (bf16_t *)cond_cl, stride, mask_out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // layout movers
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float *__restrict__ src, int N, int C, long long S,

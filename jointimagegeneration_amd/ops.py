@@ -149,6 +149,10 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     d.out = out.data_ptr()
     d.gn_scale = _ptr(prologue[0]) if prologue is not None else None
     d.gn_shift = _ptr(prologue[1]) if prologue is not None else None
+    wsb = lib.gg_conv_workspace_bytes(C.byref(d))
+    if wsb > 0:
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=t1.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
     return CL(out, cout)
 
@@ -290,3 +294,12 @@ def minmax_normalise(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> t
     ws = torch.empty(2, dtype=torch.float32, device=src.device)
     check(lib.gg_minmax_normalise(src.data_ptr(), src.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "gg_minmax_normalise")
     return out
+
+
+def mask_to_cond_slice(labels: torch.Tensor, slice_idx: int, D: int, H: int, W: int, prev: Optional[torch.Tensor],
+                       cond: torch.Tensor, mask_out: Optional[torch.Tensor] = None) -> None:
+    """labels int32 [N,Dm,Hm,Wm] -> cond bf16 CL [N,1,H,W,stride] (ch0 prev slice, ch1 mask/255)."""
+    lib = _lib.load()
+    N, Dm, Hm, Wm = labels.shape
+    check(lib.gg_mask_to_cond_slice(labels.data_ptr(), N, Dm, Hm, Wm, slice_idx, D, H, W, _ptr(prev), cond.data_ptr(), cond.shape[-1],
+                                    _ptr(mask_out), _stream()), "gg_mask_to_cond_slice")

@@ -1,0 +1,116 @@
+"""GuideGen volume pipeline on one GPU: CCDM mask (labels) -> stage glue -> autoregressive LDM slices -> CT volume.
+
+Restates the orchestration of ccdm/ddpm/evaluator.py:127-170 (x_T ~ uniform categorical, condition = zeros) and
+latentdiffusion/sample_diffusion.py:196-224 (slice loop: cond = [previous generated slice, mask slice] -> cond stage
+-> DDIM -> decode -> min-max normalise -> feed back), keeping every tensor on the device in channels-last form.
+Volumes are independent units: multi-GPU runs shard volumes over ranks with no collective.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ccdm import DenoisingModel, DiffusionModel
+from .ldm import DDIMSampler, LatentDiffusion
+from .ops import CL, pad32
+from .synth import randomize_parameters
+from .unet import create_unet_openai
+
+CCDM_PARAMS = dict(base_channels=64, channel_mult=[1, 2, 2, 4, 5], attention_resolutions=[32, 16, 8], num_heads=1,
+                   num_head_channels=32, softmax_output=True)                      # ccdm/params_eval.yml:58-64
+
+
+def ae_config(in_channels: int, ch: int) -> dict:
+    """first/cond stage of configs/latent-diffusion/ruijin-ldm_from_controlnet_ae.yaml:41-94."""
+    return dict(target="ldm.models.autoencoder.AutoencoderKL",
+                params=dict(embed_dim=4, dims=2, lossconfig=dict(target="torch.nn.Identity"),
+                            ddconfig=dict(double_z=True, z_channels=4, resolution=512, in_channels=in_channels, out_ch=in_channels,
+                                          ch=ch, ch_mult=[1, 2, 4, 4], num_res_blocks=2, dropout=0.0, dims=2, attn_resolutions=[16, 8])))
+
+
+LDM_UNET = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                params=dict(dims=2, image_size=512, in_channels=8, out_channels=4, model_channels=160, attention_resolutions=[8, 4, 2],
+                            num_res_blocks=2, channel_mult=[1, 2, 4, 4, 5], num_head_channels=32))   # …_ae.yaml:17-40
+
+
+def build_ccdm(K: int = 14, T: int = 250, seed: int = 1024, device="cuda") -> DenoisingModel:
+    unet = create_unet_openai(image_size=128, in_channels=K + 1, out_channels=K, num_res_blocks=2, cond_encoded_shape=None, dims=3,
+                              **CCDM_PARAMS)
+    randomize_parameters(unet, seed, "ccdm.")
+    return DenoisingModel(DiffusionModel("cosine", T, K, dims=3), unet, "synthetic", "majority", dims=3).eval().to(device)
+
+
+def build_ldm(seed: int = 1024, device="cuda", use_ema: bool = False) -> LatentDiffusion:
+    m = LatentDiffusion(first_stage_config=ae_config(1, 128), cond_stage_config=ae_config(2, 96), unet_config=LDM_UNET,
+                        linear_start=0.0015, linear_end=0.0195, num_timesteps_cond=1, timesteps=1000, first_stage_key="image",
+                        cond_stage_key="mask", image_size=64, channels=4, dims=2, use_ema=use_ema)
+    randomize_parameters(m, seed, "ldm.")
+    return m.eval().to(device)
+
+
+class GuideGenPipeline:
+    def __init__(self, ccdm: DenoisingModel, ldm: LatentDiffusion, ddim_steps: int = 50):
+        self.ccdm, self.ldm, self.ddim_steps = ccdm, ldm, ddim_steps
+        self.sampler = DDIMSampler(ldm)
+        self.sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
+        self.stats: Dict[str, float] = {}
+
+    # ---- stage 1 ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_mask(self, N: int, size: Tuple[int, int, int], seed: int, init_t: Optional[int] = None) -> torch.Tensor:
+        """x_T ~ uniform categorical one-hot (evaluator.py:135-136), condition = zeros; returns int32 labels [N,D,H,W]."""
+        dev = self.ccdm.diffusion.betas.device
+        K = self.ccdm.diffusion.num_classes
+        g = torch.Generator(device=dev).manual_seed(seed)
+        x_T = torch.randint(0, K, (N,) + tuple(size), generator=g, device=dev, dtype=torch.int32)
+        self.ccdm.philox_seed = seed
+        cond = torch.zeros((N, 1) + tuple(size), device=dev)
+        labels, _ = self.ccdm.sample_labels(x_T, cond, init_t)
+        return labels
+
+    # ---- stage 2 ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_ct(self, labels: torch.Tensor, depth: int, hw: int, seed: int, max_slices: Optional[int] = None) -> torch.Tensor:
+        """labels int32 [N,Dm,Hm,Wm] -> CT volume fp32 [N, depth, hw, hw] in [0,1]; slice m conditioned on slice m-1."""
+        ldm, sampler, S = self.ldm, self.sampler, self.ddim_steps
+        dev = labels.device
+        N = labels.shape[0]
+        lat = hw // 8
+        Cz = ldm.channels
+        g = torch.Generator(device=dev).manual_seed(seed)
+        samples = torch.zeros((depth, N, hw, hw), dtype=torch.float32, device=dev)        # slice-major: one slice is contiguous
+        cond_in = torch.empty((N, 1, hw, hw, 32), dtype=torch.bfloat16, device=dev)
+        # slices whose upsampled mask is non-empty (sample_diffusion.py:202); python indexing of the reference loop kept
+        Dm = labels.shape[1]
+        nz = (labels != 0).flatten(2).any(-1).any(0)                                       # [Dm]
+        idx = torch.nonzero(nz[(torch.arange(depth, device=dev) * Dm) // depth]).flatten()
+        start, end = (int(idx[0]), int(idx[-1])) if idx.numel() else (1, 0)
+        st = sampler.prepare_state(N, Cz, (lat, lat), dev, Cz)
+        todo = list(range(start - 1, end + 1))
+        if max_slices is not None:
+            todo = todo[:max_slices]
+        for m in todo:
+            mm = m % depth
+            prev = samples[max(0, m - 1) % depth]
+            ops.mask_to_cond_slice(labels, mm, depth, hw, hw, prev, cond_in)
+            mom = ldm.cond_stage_model.encode_moments_cl(CL(cond_in, 2))                   # fp32 CL [N,1,lat,lat,32]; mode() = mean
+            x_T = torch.randn((N, 1, lat, lat, Cz), generator=g, device=dev)
+            st["x"].copy_(x_T)
+            st["unet_in"][..., :Cz].copy_(x_T)                                             # plumbing: fp32 -> bf16 copy of x_T
+            st["unet_in"][..., Cz:2 * Cz].copy_(mom.t[..., :Cz])                          # c_concat = posterior mean
+            sampler.run_steps(st, None, 0.0, None)
+            z = torch.zeros((N, 1, lat, lat, 32), dtype=torch.bfloat16, device=dev)
+            z[..., :Cz].copy_(st["x"] * (1.0 / ldm.scale_factor))
+            dec = ldm.first_stage_model.decode_cl(CL(z, Cz))                               # fp32 CL [N,1,hw,hw,32]
+            ds = dec.t[..., 0].reshape(N, hw, hw).contiguous()
+            ops.minmax_normalise(ds, out=samples[mm])
+        return samples.permute(1, 0, 2, 3)
+
+    @torch.no_grad()
+    def run_volume(self, N: int = 1, mask_size=(128, 128, 128), depth: int = 256, hw: int = 512, seed: int = 1024,
+                   ccdm_init_t: Optional[int] = None, max_slices: Optional[int] = None):
+        labels = self.sample_mask(N, mask_size, seed, ccdm_init_t)
+        ct = self.sample_ct(labels, depth, hw, seed + 1, max_slices)
+        return labels, ct
