@@ -61,7 +61,8 @@ typedef struct {
     int32_t upsample;          /* 1: nearest-neighbour x2 on D(if kd==3),H,W is fused in front of the conv */
     int32_t Do, Ho, Wo;        /* output extent                                                          */
     int32_t out_dtype;         /* GG_BF16 or GG_F32                                                      */
-    int32_t prologue_act;      /* 0 none, 1: y = silu(x*gn_scale + gn_shift) applied while gathering    */
+    int32_t prologue_act;      /* fused GroupNorm prologue applied while gathering (zero padding stays zero):
+                                  0 none, 1: silu(x*gn_scale + gn_shift), 2: x*gn_scale + gn_shift        */
     int32_t reserved;
     const void *src1;          /* bf16 CL [N,D,H,W,C1]                                                   */
     const void *src2;          /* bf16 CL [N,D,H,W,C2] or NULL                                           */

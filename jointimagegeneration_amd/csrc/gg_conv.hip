@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
                     bf16x8 yb;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        yb[j] = (bf16_t)gg_silu((float)xb[j] * s0[j] + h0[j]);
-                        yb[j + 4] = (bf16_t)gg_silu((float)xb[j + 4] * s1[j] + h1[j]);
+                        float y0 = (float)xb[j] * s0[j] + h0[j], y1 = (float)xb[j + 4] * s1[j] + h1[j];
+                        if (p.prologue_act == 1) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
+                        yb[j] = (bf16_t)y0;
+                        yb[j + 4] = (bf16_t)y1;
                     }
                     v = __builtin_bit_cast(u32x4, yb);
                 }

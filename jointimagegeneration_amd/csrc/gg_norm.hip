@@ -104,6 +104,51 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
         for (int c = C_logical + tid; c < C; c += 256) { scale[(long long)n * C + c] = 0.f; shift[(long long)n * C + c] = 0.f; }
 }
 
+// Small-tensor fast path: ONE launch. Block (g, n) reduces its group's S x cpg elements (fp32 per thread, fp64 tree),
+// then writes the folded scale/shift of its channels. Used when N*S*C is small enough that launch latency, not HBM,
+// is the cost (LDM latent UNet, deep CCDM levels).
+__global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__restrict__ s1, int C1, const bf16_t *__restrict__ s2,
+                                                             int C2, long long S, int C_logical, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps, float *__restrict__ scale,
+                                                             float *__restrict__ shift)
+{
+    const int C = C1 + C2;
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C_logical / 32;
+    const long long total = S * cpg;
+    const bf16_t *b1 = s1 + (long long)n * S * C1;
+    const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
+    float a = 0.f, b = 0.f;
+    for (long long i = tid; i < total; i += 256) {
+        long long r = i / cpg;
+        int c = g * cpg + (int)(i - r * cpg);
+        float v = (c < C1) ? (float)b1[r * C1 + c] : (float)b2[r * C2 + (c - C1)];
+        a += v;
+        b += v * v;
+    }
+    __shared__ double ra[256], rb[256];
+    ra[tid] = (double)a;
+    rb[tid] = (double)b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { ra[tid] += ra[tid + s]; rb[tid] += rb[tid + s]; }
+        __syncthreads();
+    }
+    const double cnt = (double)total;
+    const double mean = ra[0] / cnt;
+    double var = rb[0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const float sc = frstd * gamma[c];
+        scale[(long long)n * C + c] = sc;
+        shift[(long long)n * C + c] = beta[c] - fmean * sc;
+    }
+    if (g == 0)
+        for (int c = C_logical + tid; c < C; c += 256) { scale[(long long)n * C + c] = 0.f; shift[(long long)n * C + c] = 0.f; }
+}
+
 extern "C" int64_t gg_groupnorm_workspace_bytes(int32_t N, int64_t S, int32_t C)
 {
     (void)S;
@@ -132,6 +177,12 @@ extern "C" int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2
     if (C_logical % 32 || C_logical > C || C_logical <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: logical channels %d not divisible by 32 groups", C_logical);
     if (C / 8 > 256) GG_FAIL(GG_ERR_UNSUPPORTED, "groupnorm: C > 2048");
     if (!src1 || (C2 && !src2) || !gamma || !beta || !scale_out || !shift_out || !workspace) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: null pointer");
+    if ((long long)S * C <= (1 << 16)) {   // tiny tensors (deep UNet levels): single-launch path
+        hipLaunchKernelGGL(gn_stats_small_kernel, dim3(32, N), dim3(256), 0, stream, (const bf16_t *)src1, C1, (const bf16_t *)src2, C2,
+                           (long long)S, C_logical, gamma, beta, eps, scale_out, shift_out);
+        GG_CHECK_LAUNCH();
+        return GG_OK;
+    }
     const int nblk = gn_nblk(N, S, C);
     if ((int64_t)N * nblk * C * 8 > workspace_bytes) GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "groupnorm: workspace %lld < %lld", (long long)workspace_bytes, (long long)N * nblk * C * 8);
     const long long rpb = (S + nblk - 1) / nblk;

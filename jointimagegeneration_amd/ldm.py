@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .blocks import AEDownsample, AEUpsample, AttnBlock2d, Normalize, ResnetBlock, gn_silu, packed_conv
+from .blocks import AEDownsample, AEUpsample, AttnBlock2d, Normalize, ResnetBlock, gn_silu, norm_conv, packed_conv
 from .config import instantiate_from_config
 from .ops import CL, pad32
 
@@ -94,9 +94,8 @@ class Encoder(nn.Module):
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample.run(h)
         h = self.mid.block_2.run(self.mid.attn_1.run(self.mid.block_1.run(h)))
-        a = gn_silu(h, self.norm_out, True)
-        pw, pb = packed_conv(self.conv_out, a.Cpad)
-        return ops.conv(a, pw, pb, self.conv_out.weight.shape[0], k=(1, 3, 3))
+        pw, pb = packed_conv(self.conv_out, h.Cpad)
+        return norm_conv(h, self.norm_out, True, pw, pb, self.conv_out.weight.shape[0], k=(1, 3, 3))
 
 
 class Decoder(nn.Module):
@@ -145,9 +144,8 @@ class Decoder(nn.Module):
                     h = lvl.attn[i_block].run(h)
             if i_level != 0:
                 h = lvl.upsample.run(h)
-        a = gn_silu(h, self.norm_out, True)
-        pw, pb = packed_conv(self.conv_out, a.Cpad)
-        return ops.conv(a, pw, pb, self.conv_out.weight.shape[0], k=(1, 3, 3), out_f32=out_f32)
+        pw, pb = packed_conv(self.conv_out, h.Cpad)
+        return norm_conv(h, self.norm_out, True, pw, pb, self.conv_out.weight.shape[0], k=(1, 3, 3), out_f32=out_f32)
 
 
 class AutoencoderKL(nn.Module):

@@ -122,7 +122,7 @@ def conv_out_extent(in_sp: Sequence[int], k: Sequence[int], stride: int, pad: in
 
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
-         bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+         bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
          out: Optional[torch.Tensor] = None) -> CL:
     lib = _lib.load()
     t1 = src1.t
@@ -139,7 +139,7 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.Do, d.Ho, d.Wo = Do, Ho, Wo
     d.out_dtype = GG_F32 if out.dtype == torch.float32 else GG_BF16
-    d.prologue_act = 1 if prologue is not None else 0
+    d.prologue_act = (1 if prologue_silu else 2) if prologue is not None else 0
     d.src1 = t1.data_ptr()
     d.src2 = _ptr(src2.t) if src2 is not None else None
     d.weight = weight.data_ptr()

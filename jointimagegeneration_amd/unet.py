@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .blocks import (AttentionBlock, Downsample, ResBlock, SpatialTransformer, TimestepEmbedSequential, Upsample, conv_nd,
-                     f32, gn_silu, normalization, packed_conv, zero_module, _k3)
+                     f32, gn_silu, norm_conv, normalization, packed_conv, zero_module, _k3)
 from .ops import CL, pad32
 
 
@@ -124,10 +124,9 @@ class _UNetBase(nn.Module):
         h = self.middle_block.run(h, tb, context)
         for module in self.output_blocks:
             h = module.run(h, tb, context, skip=hs.pop())
-        a = gn_silu(h, self.out[0], True)
         conv = self.out[2]
-        pw, pb = packed_conv(conv, a.Cpad)
-        return ops.conv(a, pw, pb, conv.weight.shape[0], k=_k3(conv.weight), out_f32=True, out=head_out)
+        pw, pb = packed_conv(conv, h.Cpad)
+        return norm_conv(h, self.out[0], True, pw, pb, conv.weight.shape[0], k=_k3(conv.weight), out_f32=True, out=head_out)
 
 
 class CCDMUNetModel(_UNetBase):
