@@ -92,7 +92,8 @@ def cpu_baseline():
     from jointimagegeneration_amd.synth import randomize_parameters
     from jointimagegeneration_amd.unet import create_unet_openai
     from oracle import nets as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share of the host; os.cpu_count() reports the whole host there
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("GG_CPU_CORES", "16")))
     torch.set_num_threads(cores)
     with torch.no_grad():
         u = create_unet_openai(image_size=128, in_channels=15, out_channels=14, num_res_blocks=2, cond_encoded_shape=None, dims=3, **CCDM_PARAMS)
@@ -133,7 +134,13 @@ def main():
     _lib.load()
     torch.set_grad_enabled(False)
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log("building models (random-init weights from the seed recipe)")
     pipe = GuideGenPipeline(build_ccdm(14, args.ccdm_steps, 1024, device), build_ldm(1024, device), ddim_steps=50)
+    log("models ready; untimed warm-up (weight repack, hipGraph capture)")
 
     def one_volume(i):
         return pipe.run_volume(N=1, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=1024 + rank + 1000 * i,
@@ -150,6 +157,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    log(f"timed region: {args.steps} volume(s)")
     t0 = time.time()
     for i in range(args.steps):
         one_volume(i)
@@ -173,6 +181,8 @@ def main():
         }
         if partial:
             line["partial"] = True
+        line["stage_seconds"] = {k: round(v, 2) for k, v in pipe.stats.items()}
+        log("measuring roofline / cpu baseline")
         if not args.no_roofline:
             line["roofline"] = conv_roofline(pipe, device)
         if not args.no_cpu_baseline:

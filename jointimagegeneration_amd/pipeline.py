@@ -7,6 +7,8 @@ Volumes are independent units: multi-GPU runs shard volumes over ranks with no c
 """
 from __future__ import annotations
 
+import sys
+import time
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -50,7 +52,13 @@ def build_ldm(seed: int = 1024, device="cuda", use_ema: bool = False) -> LatentD
     return m.eval().to(device)
 
 
+def _log(msg: str) -> None:
+    print(f"[guidegen {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 class GuideGenPipeline:
+    progress_every_s = 30.0
+
     def __init__(self, ccdm: DenoisingModel, ldm: LatentDiffusion, ddim_steps: int = 50):
         self.ccdm, self.ldm, self.ddim_steps = ccdm, ldm, ddim_steps
         self.sampler = DDIMSampler(ldm)
@@ -91,7 +99,11 @@ class GuideGenPipeline:
         todo = list(range(start - 1, end + 1))
         if max_slices is not None:
             todo = todo[:max_slices]
-        for m in todo:
+        t_last = time.time()
+        for it, m in enumerate(todo):
+            if time.time() - t_last > self.progress_every_s:
+                _log(f"LDM slice {it}/{len(todo)}")
+                t_last = time.time()
             mm = m % depth
             prev = samples[max(0, m - 1) % depth]
             ops.mask_to_cond_slice(labels, mm, depth, hw, hw, prev, cond_in)
@@ -111,6 +123,12 @@ class GuideGenPipeline:
     @torch.no_grad()
     def run_volume(self, N: int = 1, mask_size=(128, 128, 128), depth: int = 256, hw: int = 512, seed: int = 1024,
                    ccdm_init_t: Optional[int] = None, max_slices: Optional[int] = None):
+        t0 = time.time()
         labels = self.sample_mask(N, mask_size, seed, ccdm_init_t)
+        torch.cuda.synchronize()
+        t1 = time.time()
         ct = self.sample_ct(labels, depth, hw, seed + 1, max_slices)
+        torch.cuda.synchronize()
+        self.stats = {"ccdm_s": t1 - t0, "ldm_s": time.time() - t1}
+        _log(f"volume done: CCDM {t1 - t0:.1f}s, LDM {time.time() - t1:.1f}s")
         return labels, ct
