@@ -126,9 +126,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    from jointimagegeneration_amd import distributed as ggd
+    ggd.init("nccl", device)
     from jointimagegeneration_amd import _lib
     from jointimagegeneration_amd.pipeline import GuideGenPipeline, build_ccdm, build_ldm
     _lib.load()
@@ -140,6 +139,9 @@ def main():
 
     log("building models (random-init weights from the seed recipe)")
     pipe = GuideGenPipeline(build_ccdm(14, args.ccdm_steps, 1024, device), build_ldm(1024, device), ddim_steps=50)
+    if os.environ.get("GG_NO_GRAPH") == "1":          # profiling aid: rocprofv3 --kernel-trace aborts on long hipGraph replays
+        pipe.ccdm.use_graph = False
+        pipe.sampler.use_graph = False
     log("models ready; untimed warm-up (weight repack, hipGraph capture)")
 
     def one_volume(i):
@@ -151,22 +153,8 @@ def main():
     for i in range(args.warmup):
         one_volume(-1 - i)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
     log(f"timed region: {args.steps} volume(s)")
-    t0 = time.time()
-    for i in range(args.steps):
-        one_volume(i)
-    barrier()
-    elapsed = time.time() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ggd.timed_region(lambda: [one_volume(i) for i in range(args.steps)], device)
 
     if rank == 0:
         partial = args.max_slices is not None or args.ccdm_steps != 250 or args.slices != 256
@@ -188,9 +176,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    ggd.finalize()
 
 
 if __name__ == "__main__":
