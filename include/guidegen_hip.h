@@ -87,6 +87,9 @@ int gg_conv_pack_weight(const float *w_f32, int32_t Cout, int32_t Cin, int32_t C
                         void *packed_bf16, void *stream);
 /* Scratch bytes gg_conv_forward needs for this shape (0 for most; > 0 when the under-filled grid is split over K). */
 int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
+/* 1 if this shape runs on the halo-tile kernel, where the GroupNorm prologue is applied once per staged element (callers
+ * then skip the separate gg_groupnorm_apply pass); 0 if it runs on the generic gather kernel. Pointers are not read. */
+int gg_conv_fuses_prologue(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

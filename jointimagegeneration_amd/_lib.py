@@ -44,6 +44,7 @@ SIGNATURES = {
     "gg_conv_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "gg_conv_forward": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "gg_conv_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
+    "gg_conv_fuses_prologue": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_groupnorm_workspace_bytes": (i64, [i32, i64, i32]),
     "gg_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i64, vp]),
     "gg_groupnorm_apply": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, vp, i32, vp, vp]),

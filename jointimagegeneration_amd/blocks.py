@@ -95,15 +95,13 @@ def gn_silu(h: CL, norm: nn.GroupNorm, act: bool, src2: Optional[CL] = None) -> 
     return ops.groupnorm_apply(h, scale, shift, act, src2)
 
 
-FUSE_PROLOGUE_MAX_POSITIONS = 0          # measured: fusing SiLU into the latency-bound gather loop is slower (26 vs 16.6 us/conv)
-
-
 def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Optional[CL] = None, **conv_kw) -> CL:
-    """conv(act(GroupNorm(cat[h, src2]))).  Small tensors (launch-latency bound): one stats launch, normalise*affine(+SiLU)
-    fused into the conv's gather prologue, concat fused as the second source.  Large tensors: separate apply pass (the
-    gather kernel would redo the SiLU once per tap; the halo kernel fuses it without that redundancy)."""
+    """conv(act(GroupNorm(cat[h, src2]))).
+    Halo-tile convs (3x3(x3), stride 1, large extents): one stats pass, then normalise*affine(+SiLU) and the skip concat are
+    fused into the conv's staging pass (applied once per staged element) -- the activation is never re-written to HBM.
+    Gather-kernel convs: separate apply pass (measured: SiLU inside the latency-bound gather loop costs 26 vs 16.6 us/conv)."""
     scale, shift = ops.groupnorm_stats(h, f32(norm.weight), f32(norm.bias), norm.eps, src2)
-    if h.N * h.S <= FUSE_PROLOGUE_MAX_POSITIONS:
+    if ops.conv_fuses_prologue(h, cout, src2=src2, **conv_kw):
         return ops.conv(h, weight, bias, cout, src2=src2, prologue=(scale, shift), prologue_silu=act, **conv_kw)
     a = ops.groupnorm_apply(h, scale, shift, act, src2)
     return ops.conv(a, weight, bias, cout, **conv_kw)

@@ -12,27 +12,9 @@
 //                  two-source concat, optional GroupNorm*SiLU prologue), staged through registers into a
 //                  swizzled, double-buffered LDS tile.
 //   conv_halo    : fast path for 3x3(x3) stride-1 convs on large extents (see gg_conv_halo.hip).
-#include "gg_common.h"
+#include "gg_conv.h"
 
-struct ConvParams {
-    int N, D, H, W, C1, C2, Cout, Cout_pad;
-    int kd, kh, kw, stride, pad, upsample;
-    int Do, Ho, Wo, out_dtype, prologue_act;
-    int nchunk1, nchunk, ntaps;
-    long long M;              // N*Do*Ho*Wo
-    long long bias_stride;
-    const bf16_t *src1, *src2, *weight, *residual;
-    const float *bias, *gn_scale, *gn_shift;
-    void *out;
-    float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
-    int splitk;
-};
-
-// 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = l&15, chunk = l>>4):
-// conflict-free for 16 consecutive rows (derivation in DESIGN.md, "LDS images").
-__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
-
-template <int NT>
+template <int NT, int PF>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
 {
     constexpr int BM = 128;
@@ -74,8 +56,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     const int upHW = p.upsample ? 1 : 0;
     const int limD = p.D << upD, limH = p.H << upHW, limW = p.W << upHW;
 
-    u32x4 xreg[2];
-    u32x4 wreg[WITER];
+    // register prefetch ring: PF k-steps of global loads are in flight (the loop is otherwise one load latency per k-step)
+    u32x4 xreg[PF][2];
+    u32x4 wreg[PF][WITER];
+    long long xso[PF][2];       // GroupNorm scale/shift offset of the piece, -1: padding / out of range (stays zero)
 
     // split-K: blockIdx.z owns k-steps [ks_begin, ks_end) of the (chunk outer, tap inner) sequence
     const int KS_all = p.ntaps * p.nchunk;
@@ -84,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     int chunk = ks_begin / p.ntaps, tap = ks_begin - (ks_begin / p.ntaps) * p.ntaps;   // counters for the NEXT global load
     int tkd = tap / (p.kh * p.kw), tkh = (tap / p.kw) % p.kh, tkw = tap % p.kw;
 
-    auto load_regs = [&]() {
+    auto load_regs = [&](u32x4 (&xr)[2], u32x4 (&wr)[WITER], long long (&so)[2]) {
         const bool second = chunk >= p.nchunk1;
         const bf16_t *src = second ? p.src2 : p.src1;
         const int Cs = second ? p.C2 : p.C1;
@@ -94,29 +78,14 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
             int ud = bd[i] + tkd, uh = bh[i] + tkh, uw = bw[i] + tkw;
             bool ok = rv[i] && ud >= 0 && ud < limD && uh >= 0 && uh < limH && uw >= 0 && uw < limW;
             u32x4 v = {0u, 0u, 0u, 0u};
+            so[i] = -1;
             if (ok) {
                 int id = ud >> upD, ih = uh >> upHW, iw = uw >> upHW;
                 long long off = ((((long long)bn[i] * p.D + id) * p.H + ih) * p.W + iw) * Cs + cc * 32 + xq * 8;
                 v = *reinterpret_cast<const u32x4 *>(src + off);
-                if (p.prologue_act) {
-                    const long long so = (long long)bn[i] * (p.C1 + p.C2) + chunk * 32 + xq * 8;
-                    f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so);
-                    f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so + 4);
-                    f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so);
-                    f32x4 h1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
-                    bf16x8 xb = __builtin_bit_cast(bf16x8, v);
-                    bf16x8 yb;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float y0 = (float)xb[j] * s0[j] + h0[j], y1 = (float)xb[j + 4] * s1[j] + h1[j];
-                        if (p.prologue_act == 1) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
-                        yb[j] = (bf16_t)y0;
-                        yb[j + 4] = (bf16_t)y1;
-                    }
-                    v = __builtin_bit_cast(u32x4, yb);
-                }
+                so[i] = (long long)bn[i] * (p.C1 + p.C2) + chunk * 32 + xq * 8;
             }
-            xreg[i] = v;
+            xr[i] = v;
         }
 #pragma unroll
         for (int j = 0; j < WITER; ++j) {
@@ -124,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
             if (i < NT * 128) {
                 int g = i >> 7, pc = i & 127;
                 long long off = ((((long long)(g0 + g) * p.ntaps + tap) * p.nchunk + chunk) << 10) + pc * 8;
-                wreg[j] = *reinterpret_cast<const u32x4 *>(p.weight + off);
+                wr[j] = *reinterpret_cast<const u32x4 *>(p.weight + off);
             }
         }
         // advance (chunk outer, tap inner)
@@ -138,21 +107,35 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         }
     };
 
-    auto write_lds = [&](int buf) {
+    auto write_lds = [&](int buf, u32x4 (&xr)[2], u32x4 (&wr)[WITER], long long (&so)[2]) {
         char *xb = smem + buf * STAGE;
         char *wb = xb + XBYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int r = (tid >> 2) + 64 * i;
-            *reinterpret_cast<u32x4 *>(xb + r * 64 + swz64(r, xq) * 16) = xreg[i];
+            u32x4 v = xr[i];
+            if (p.prologue_act && so[i] >= 0) {   // fused GroupNorm(*SiLU): y = act(x*scale + shift); zero padding stays zero
+                f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so[i]);
+                f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so[i] + 4);
+                f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so[i]);
+                f32x4 h1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so[i] + 4);
+                bf16x8 xb8 = __builtin_bit_cast(bf16x8, v);
+                bf16x8 yb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y0 = (float)xb8[j] * s0[j] + h0[j], y1 = (float)xb8[j + 4] * s1[j] + h1[j];
+                    if (p.prologue_act == 1) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
+                    yb[j] = (bf16_t)y0;
+                    yb[j + 4] = (bf16_t)y1;
+                }
+                v = __builtin_bit_cast(u32x4, yb);
+            }
+            *reinterpret_cast<u32x4 *>(xb + r * 64 + swz64(r, xq) * 16) = v;
         }
 #pragma unroll
         for (int j = 0; j < WITER; ++j) {
             int i = tid + 256 * j;
-            if (i < NT * 128) {
-                int r = i >> 2, q = i & 3;
-                *reinterpret_cast<u32x4 *>(wb + r * 64 + swz64(r, q) * 16) = wreg[j];
-            }
+            if (i < NT * 128) *reinterpret_cast<u32x4 *>(wb + i * 16) = wr[j];   // image pre-swizzled at pack time
         }
     };
 
@@ -183,15 +166,21 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     };
 
     const int KS = ks_end - ks_begin;
-    load_regs();
-    write_lds(0);
-    __syncthreads();
-    for (int ks = 0; ks < KS; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < KS) load_regs();
-        compute(cur);
-        if (ks + 1 < KS) write_lds(cur ^ 1);
-        __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (j < KS) load_regs(xreg[j], wreg[j], xso[j]);
+    for (int ks0 = 0; ks0 < KS; ks0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int ks = ks0 + j;
+            if (ks < KS) {
+                const int buf = ks & 1;
+                write_lds(buf, xreg[j], wreg[j], xso[j]);       // waits only for slot j's loads (counted vmcnt)
+                __syncthreads();                                 // one barrier per k-step: a wave that passed barrier(ks+1)
+                if (ks + PF < KS) load_regs(xreg[j], wreg[j], xso[j]);   // knows every wave finished compute(ks) => buf reuse at ks+2 is safe
+                compute(buf);
+            }
+        }
     }
 
     if (p.splitk > 1) {   // raw fp32 partial tile -> slab; bias/residual/cast happen in conv_splitk_reduce_kernel
@@ -294,7 +283,9 @@ __global__ void conv_pack_weight_kernel(const float *__restrict__ w, int Cout, i
         t /= nchunk;
         int tap = (int)(t % ntaps);
         int g = (int)(t / ntaps);
-        int co = g * 32 + col, ci = chunk * 32 + cil;
+        // physical 16-byte slot (cil>>3) of row `col` holds the LOGICAL chunk swz64(col, slot) (involution): the linear LDS
+        // image of a tile is then bank-conflict free for ds_read_b128 without any swizzle at staging time
+        int co = g * 32 + col, ci = chunk * 32 + swz64(col, cil >> 3) * 8 + (cil & 7);
         float v = 0.f;
         if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * ntaps + tap];
         dst[i] = (bf16_t)v;
@@ -328,7 +319,7 @@ template <int NT>
 static int launch_gather(const ConvParams &p, hipStream_t stream)
 {
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.Cout_pad / (32 * NT)), (unsigned)p.splitk);
-    hipLaunchKernelGGL(conv_gather_kernel<NT>, grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_gather_kernel<NT, (NT <= 2 ? 4 : 2)>), grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
     if (p.splitk > 1) {
         long long total = p.M * (p.Cout_pad / 4);
@@ -372,6 +363,29 @@ extern "C" int64_t gg_conv_workspace_bytes(const gg_conv_desc *d)
     return pl.splitk > 1 ? (int64_t)pl.splitk * M * d->Cout_pad * 4 : 0;
 }
 
+static void fill_params(const gg_conv_desc *d, ConvParams &p)
+{
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Cout = d->Cout; p.Cout_pad = d->Cout_pad;
+    p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.upsample = d->upsample;
+    p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.prologue_act = d->prologue_act;
+    p.nchunk1 = d->C1 / 32; p.nchunk = (d->C1 + d->C2) / 32; p.ntaps = d->kd * d->kh * d->kw;
+    p.M = (long long)d->N * d->Do * d->Ho * d->Wo;
+    p.bias_stride = d->bias_stride;
+    p.src1 = (const bf16_t *)d->src1; p.src2 = (const bf16_t *)d->src2; p.weight = (const bf16_t *)d->weight;
+    p.residual = (const bf16_t *)d->residual; p.bias = d->bias; p.gn_scale = d->gn_scale; p.gn_shift = d->gn_shift;
+    p.out = d->out;
+    p.ws = nullptr;
+    p.splitk = 1;
+}
+
+extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK ? 1 : 0;
+}
+
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -399,17 +413,7 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
                 d->Do, d->Ho, d->Wo, d->D, d->H, d->W, d->kd, d->kh, d->kw, d->stride, d->pad, d->upsample);
 
     ConvParams p;
-    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Cout = d->Cout; p.Cout_pad = d->Cout_pad;
-    p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.upsample = d->upsample;
-    p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.prologue_act = d->prologue_act;
-    p.nchunk1 = d->C1 / 32; p.nchunk = (d->C1 + d->C2) / 32; p.ntaps = d->kd * d->kh * d->kw;
-    p.M = (long long)d->N * d->Do * d->Ho * d->Wo;
-    p.bias_stride = d->bias_stride;
-    p.src1 = (const bf16_t *)d->src1; p.src2 = (const bf16_t *)d->src2; p.weight = (const bf16_t *)d->weight;
-    p.residual = (const bf16_t *)d->residual; p.bias = d->bias; p.gn_scale = d->gn_scale; p.gn_shift = d->gn_shift;
-    p.out = d->out;
-    p.ws = nullptr;
-    p.splitk = 1;
+    fill_params(d, p);
 
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;

@@ -1,4 +1,253 @@
-// Halo-tile fast path for 3x3(x3) stride-1 convolutions (placeholder until the tuned kernel lands).
-#include "gg_common.h"
-struct ConvParams;
-int gg_conv_halo_try(const ConvParams &, hipStream_t) { return GG_ERR_UNSUPPORTED; }
+// Halo-tile implicit-GEMM convolution for gfx950: 3x3(x3), stride 1, pad 1 (optionally with the nearest x2 upsample
+// fused in front), bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// One workgroup (4 waves) owns an output box of 256 positions (3-D: 4x4x16, 2-D: 1x16x16) x BN = 32*NT output channels.
+// Per 32-channel chunk of the input:
+//   1. the INPUT box that the 27 (9) taps touch (3-D: 6x6x18 rows, 2-D: 18x18; upsample: 4x4x10 / 10x10) is staged ONCE into
+//      LDS as 64-byte rows (zero padding, two-source concat, and GroupNorm*SiLU applied here, once per element);
+//   2. for every tap the 32x(32*NT) weight tile is streamed into a double-buffered LDS slot by global_load_lds (the packed
+//      weight is pre-swizzled, so the linear DMA image is already the bank-conflict-free one) while the previous tap's
+//      MFMAs run; the activation operand of tap (kd,kh,kw) is the same LDS box read at a shifted row.
+// HBM/L2 traffic per block and chunk: one box (41 KB) instead of 27 gathered tiles (27 x 16 KB) in the generic kernel.
+#include "gg_conv.h"
+#include <stdlib.h>
+
+template <int D3, int NT, int UP>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+{
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 4 : 16, TW = 16;
+    constexpr int KD = D3 ? 3 : 1;
+    constexpr int NTAPS = KD * 9;
+    constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1;
+    constexpr int HH = UP ? TH / 2 + 2 : TH + 2;
+    constexpr int HW = UP ? TW / 2 + 2 : TW + 2;
+    constexpr int NROWS = HD * HH * HW;
+    constexpr int NPIECE = NROWS * 4;
+    constexpr int JMAX = (NPIECE + 255) / 256;
+    constexpr int XBYTES = ((NROWS * 64 + 1023) / 1024) * 1024;
+    constexpr int WBYTES = NT * 2048;                    // one tap: 32*NT cout rows x 64 B
+    __shared__ __attribute__((aligned(1024))) char smem[XBYTES + 2 * WBYTES];
+    char *xs = smem;
+    char *wsm = smem + XBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- tile coordinates; consecutive (remapped) block ids walk W, then H, then D tiles: neighbours share their halo in L2.
+    // XCD-aware remap (blocks b and b+8 share an XCD): give every XCD a contiguous run of tiles when the grid allows it.
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    int t = bid;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int td = t % tiles_d;
+    const int n = t / tiles_d;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;          // output-box origin
+    const int g0 = blockIdx.y * NT;
+
+    // input coordinates of halo row (0,0,0)
+    const int id0 = D3 ? (UP ? d0 / 2 - 1 : d0 - 1) : 0;
+    const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
+    const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
+
+    // ---- per-thread staging duties (piece = 16 B = 8 channels; q is the same for all of a thread's pieces)
+    const int xq = tid & 3;
+    int soff[JMAX];                  // position index of the piece's row in the source tensor, or -1 (zero padding)
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int i = tid + 256 * j;
+        const int row = i >> 2;
+        soff[j] = -1;
+        if (i < NPIECE) {
+            const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+            const int hh = rem / HW, hw = rem - hh * HW;
+            const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+            if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                soff[j] = ((n * p.D + id) * p.H + ih) * p.W + iw;
+        }
+    }
+
+    // ---- per-lane activation-operand row offsets: row(tap) = RD(tile,kd) + RH(tile,kh) + rw[kw]; only rw depends on the lane
+    int rw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rw[k] = UP ? ((fr + k + 1) >> 1) : (fr + k);
+
+    f32x4 acc[4][2 * NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight tile DMA: tile (g0.., tap, chunk) is NT contiguous 2 KiB groups strided by ntaps*nchunk*2 KiB
+    auto issue_w = [&](int ks, int buf) {
+        const int chunk = ks / NTAPS, tap = ks - chunk * NTAPS;
+#pragma unroll
+        for (int i = 0; i < (NT * 2 + 3) / 4; ++i) {
+            const int piece1k = wave + 4 * i;                   // which 1 KiB piece of the NT*2 KiB tile this wave moves
+            if (piece1k < NT * 2) {
+                const int g = piece1k >> 1, half = piece1k & 1;
+                const bf16_t *src = p.weight + ((((long long)(g0 + g) * NTAPS + tap) * p.nchunk + chunk) << 10) + half * 512 + lane * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(wsm + buf * WBYTES + piece1k * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    const int KS = p.nchunk * NTAPS;
+    issue_w(0, 0);
+
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        // ================= stage the input box of this chunk (all threads) =================
+        {
+            const bool second = chunk >= p.nchunk1;
+            const bf16_t *src = second ? p.src2 : p.src1;
+            const int Cs = second ? p.C2 : p.C1;
+            const int coff = (second ? chunk - p.nchunk1 : chunk) * 32 + xq * 8;
+            u32x4 v[JMAX];
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                v[j] = u32x4{0u, 0u, 0u, 0u};
+                if (soff[j] >= 0) v[j] = *reinterpret_cast<const u32x4 *>(src + (long long)soff[j] * Cs + coff);
+            }
+            if (p.prologue_act) {
+                const long long so = (long long)n * (p.C1 + p.C2) + chunk * 32 + xq * 8;
+                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so), s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so), b1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) {
+                    if (soff[j] >= 0) {
+                        bf16x8 xb = __builtin_bit_cast(bf16x8, v[j]);
+                        bf16x8 yb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float y0 = (float)xb[e] * s0[e] + b0[e], y1 = (float)xb[e + 4] * s1[e] + b1[e];
+                            if (p.prologue_act == 1) {
+                                y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                                y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                            }
+                            yb[e] = (bf16_t)y0;
+                            yb[e + 4] = (bf16_t)y1;
+                        }
+                        v[j] = __builtin_bit_cast(u32x4, yb);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                if (tid + 256 * j < NPIECE) {
+                    const int row = (tid >> 2) + 64 * j;
+                    *reinterpret_cast<u32x4 *>(xs + row * 64 + swz64(row, xq) * 16) = v[j];
+                }
+        }
+        __syncthreads();          // box visible; (vmcnt(0) inside: the first weight tile of the chunk has landed too)
+
+        // keep the 27x4 operand addresses from being hoisted out of the chunk loop (they would pin >100 VGPRs)
+        asm volatile("" : "+v"(rw[0]), "+v"(rw[1]), "+v"(rw[2]));
+        // ================= 27 (9) taps from LDS =================
+#pragma unroll 1
+        for (int kd = 0; kd < KD; ++kd) {
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int tap = kd * 9 + t9;
+                const int ks = chunk * NTAPS + tap;
+                if (ks + 1 < KS) issue_w(ks + 1, (ks + 1) & 1);
+                const int kh = t9 / 3, kw = t9 % 3;
+                const char *wb = wsm + (ks & 1) * WBYTES;
+                bf16x8 xf[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int tile = wave * 4 + tt;                 // one W-row of 16 output positions
+                    const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+                    const int hd = D3 ? (UP ? ((od + kd + 1) >> 1) : od + kd) : 0;
+                    const int hh = UP ? ((oh + kh + 1) >> 1) : oh + kh;
+                    const int row = (hd * HH + hh) * HW + rw[kw];
+                    xf[tt] = *reinterpret_cast<const bf16x8 *>(xs + row * 64 + swz64(row, fq) * 16);
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2 * NT; ++ct) {
+                    const int r = ct * 16 + fr;
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);   // image pre-swizzled at pack time
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[tt], acc[tt][ct], 0, 0, 0);
+                }
+                __syncthreads();      // next tap's weights landed (vmcnt(0)); this tap's slot / the box may be overwritten
+            }
+        }
+    }
+
+    // ================= epilogue: + bias[n] (+ residual) -> bf16 / fp32 =================
+    const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int tile = wave * 4 + tt;
+        const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+        const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
+#pragma unroll
+        for (int ct = 0; ct < 2 * NT; ++ct) {
+            const int co = g0 * 32 + ct * 16 + fq * 4;
+            f32x4 v = acc[tt][ct];
+            if (brow) v += *reinterpret_cast<const f32x4 *>(brow + co);
+            const long long o = m * p.Cout_pad + co;
+            if (p.residual) {
+                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co + j >= p.Cout) v[j] = 0.f;
+            if (p.out_dtype == GG_F32) {
+                *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+            } else {
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+            }
+        }
+    }
+}
+
+template <int D3, int NT, int UP>
+static int launch_halo(const ConvParams &p, hipStream_t stream)
+{
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 4 : 16, TW = 16;
+    const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
+    dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(256), 0, stream, p, tiles_d, tiles_h, tiles_w);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+template <int D3, int UP>
+static int dispatch_nt(const ConvParams &p, int NT, hipStream_t stream)
+{
+    switch (NT) {
+        case 4: return launch_halo<D3, 4, UP>(p, stream);
+        case 3: return launch_halo<D3, 3, UP>(p, stream);
+        case 2: return launch_halo<D3, 2, UP>(p, stream);
+        default: return launch_halo<D3, 1, UP>(p, stream);
+    }
+}
+
+// Returns GG_ERR_UNSUPPORTED (silently, no error text) when the shape is outside the envelope: the caller then uses the
+// generic gather kernel.  stream == (hipStream_t)-1: dry run (only answers whether the halo kernel would be used).
+int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
+{
+    const bool d3 = (p.kd == 3);
+    if (!(p.kh == 3 && p.kw == 3 && (p.kd == 3 || p.kd == 1))) return GG_ERR_UNSUPPORTED;
+    if (p.stride != 1 || p.pad != 1) return GG_ERR_UNSUPPORTED;
+    if (!d3 && p.D != 1) return GG_ERR_UNSUPPORTED;
+    const int TD = d3 ? 4 : 1, TH = d3 ? 4 : 16, TW = 16;
+    if (p.Wo % TW || p.Ho % TH || p.Do % TD) return GG_ERR_UNSUPPORTED;
+    const int G = p.Cout_pad / 32;
+    const int NT = (G % 4 == 0) ? 4 : (G % 3 == 0) ? 3 : (G % 2 == 0) ? 2 : 1;
+    const long long blocks = (long long)p.N * (p.Do / TD) * (p.Ho / TH) * (p.Wo / TW) * (G / NT);
+    static const long long min_blocks = [] { const char *e = getenv("GG_HALO_MIN_BLOCKS"); return e ? atoll(e) : 128LL; }();
+    if (blocks < min_blocks) return GG_ERR_UNSUPPORTED;    // under-filled grid: split-K gather path is faster
+    if (stream == (hipStream_t)-1) return GG_OK;
+    if (d3) return p.upsample ? dispatch_nt<1, 1>(p, NT, stream) : dispatch_nt<1, 0>(p, NT, stream);
+    return p.upsample ? dispatch_nt<0, 1>(p, NT, stream) : dispatch_nt<0, 0>(p, NT, stream);
+}

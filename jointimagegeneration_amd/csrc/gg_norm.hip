@@ -177,7 +177,7 @@ extern "C" int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2
     if (C_logical % 32 || C_logical > C || C_logical <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: logical channels %d not divisible by 32 groups", C_logical);
     if (C / 8 > 256) GG_FAIL(GG_ERR_UNSUPPORTED, "groupnorm: C > 2048");
     if (!src1 || (C2 && !src2) || !gamma || !beta || !scale_out || !shift_out || !workspace) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm: null pointer");
-    if ((long long)S * C <= (1 << 16)) {   // tiny tensors (deep UNet levels): single-launch path
+    if ((long long)S * C <= (1 << 19)) {   // small tensors (deep UNet levels): single-launch path
         hipLaunchKernelGGL(gn_stats_small_kernel, dim3(32, N), dim3(256), 0, stream, (const bf16_t *)src1, C1, (const bf16_t *)src2, C2,
                            (long long)S, C_logical, gamma, beta, eps, scale_out, shift_out);
         GG_CHECK_LAUNCH();

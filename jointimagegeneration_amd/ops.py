@@ -120,6 +120,22 @@ def conv_out_extent(in_sp: Sequence[int], k: Sequence[int], stride: int, pad: in
     return tuple(out)
 
 
+def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
+                        src2: Optional[CL] = None, **_ignored) -> bool:
+    """True if this conv runs on the halo-tile kernel (GroupNorm prologue applied once per element while staging)."""
+    lib = _lib.load()
+    N, D, H, W, C1 = src1.t.shape
+    Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
+    d = ConvDesc()
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = C1, (src2.t.shape[-1] if src2 is not None else 0)
+    d.Cout, d.Cout_pad = cout, pad32(cout)
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    return bool(lib.gg_conv_fuses_prologue(C.byref(d)))
+
+
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,

@@ -79,6 +79,63 @@ def test_conv_matches_oracle(dev, case):
         assert float(out.t[..., Cout:].float().abs().max()) == 0.0
 
 
+HALO_CASES = [
+    # name, dims, N, Cin, Cout, spatial(in), upsample   (3x3(x3), stride 1, pad 1; extents tile exactly: halo kernel)
+    ("h3d_nt2", 3, 1, 64, 64, (8, 8, 32), False),
+    ("h3d_nt4", 3, 2, 32, 128, (4, 8, 16), False),
+    ("h3d_nt3_cin15", 3, 1, 15, 96, (8, 4, 16), False),
+    ("h3d_head_f32", 3, 1, 64, 14, (4, 8, 16), False),
+    ("h3d_up", 3, 1, 64, 64, (4, 4, 8), True),
+    ("h2d_nt2", 2, 1, 160, 320, (32, 32), False),
+    ("h2d_nt4", 2, 2, 96, 128, (16, 48), False),
+    ("h2d_up", 2, 1, 128, 128, (16, 8), True),
+    ("h2d_cout1", 2, 1, 128, 1, (32, 16), False),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_conv_halo_kernel_matches_oracle(dev, case, monkeypatch):
+    """Same oracle, but shapes inside the halo-tile kernel's envelope (GG_HALO_MIN_BLOCKS=1 lifts the grid-size gate)."""
+    from jointimagegeneration_amd import ops
+    name, dims, N, Cin, Cout, sp, up = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn((N, Cin) + sp, generator=g)
+    w = torch.randn((Cout, Cin) + (3,) * dims, generator=g) / math.sqrt(Cin * 3 ** dims)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = O.conv(O.upsample_nearest2(bf(x)) if up else bf(x), bf(w), b, padding=1)
+    xcl = ops.to_cl(x.to(dev))
+    pw = ops.pack_conv_weight(w.to(dev), xcl.Cpad)
+    out = ops.conv(xcl, pw, ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1,) * (3 - dims) + (3,) * dims, upsample=up, out_f32=(Cout == 14))
+    got = ops.from_cl(out, dims).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-2, rel_err(got, ref)
+    if out.Cpad > Cout:
+        assert float(out.t[..., Cout:].float().abs().max()) == 0.0
+
+
+def test_conv_halo_two_source_prologue_residual(dev):
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(6)
+    N, C1, C2, Cout, sp = 2, 64, 32, 64, (4, 8, 16)
+    x1, x2 = torch.randn((N, C1) + sp, generator=g), torch.randn((N, C2) + sp, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g) / math.sqrt((C1 + C2) * 27)
+    tb = torch.randn(N, Cout, generator=g)
+    res = torch.randn((N, Cout) + sp, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C1 + C2, generator=g), 0.1 * torch.randn(C1 + C2, generator=g)
+    xc = torch.cat([bf(x1), bf(x2)], 1)
+    c1, c2 = ops.to_cl(x1.to(dev)), ops.to_cl(x2.to(dev))
+    scale, shift = ops.groupnorm_stats(c1, gamma.to(dev), beta.to(dev), 1e-5, src2=c2)
+    pw = ops.pack_conv_weight(w.to(dev), C1 + C2)
+    tbp = torch.zeros(N, ops.pad32(Cout), device=dev); tbp[:, :Cout] = tb.to(dev)
+    for silu in (True, False):
+        a = O.group_norm(xc, gamma, beta, 1e-5)
+        a = O.silu(a) if silu else a
+        ref = O.conv(bf(a), bf(w), None, padding=1) + tb[:, :, None, None, None] + bf(res)
+        out = ops.conv(c1, pw, tbp, Cout, k=(3, 3, 3), src2=c2, residual=ops.to_cl(res.to(dev)), bias_per_sample=True,
+                       prologue=(scale, shift), prologue_silu=silu)
+        assert rel_err(ops.from_cl(out, 3), ref) < 1.5e-2
+
+
 def test_conv_two_source_residual_per_sample_bias_prologue(dev):
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(5)
