@@ -1,9 +1,9 @@
 // Halo-tile implicit-GEMM convolution for gfx950: 3x3(x3), stride 1, pad 1 (optionally with the nearest x2 upsample
 // fused in front), bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
 //
-// One workgroup (4 waves) owns an output box of 256 positions (3-D: 4x4x16, 2-D: 1x16x16) x BN = 32*NT output channels.
+// One workgroup (8 waves) owns an output box of 512 positions (3-D: 4x8x16, 2-D: 1x32x16) x BN = 32*NT output channels.
 // Per 32-channel chunk of the input:
-//   1. the INPUT box that the 27 (9) taps touch (3-D: 6x6x18 rows, 2-D: 18x18; upsample: 4x4x10 / 10x10) is staged ONCE into
+//   1. the INPUT box that the 27 (9) taps touch (3-D: 6x10x18 rows, 2-D: 34x18; upsample: 4x6x10 / 18x10) is staged ONCE into
 //      LDS as 64-byte rows (zero padding, two-source concat, and GroupNorm*SiLU applied here, once per element);
 //   2. for every tap the 32x(32*NT) weight tile is streamed into a double-buffered LDS slot by global_load_lds (the packed
 //      weight is pre-swizzled, so the linear DMA image is already the bank-conflict-free one) while the previous tap's
@@ -11,11 +11,15 @@
 // HBM/L2 traffic per block and chunk: one box (41 KB) instead of 27 gathered tiles (27 x 16 KB) in the generic kernel.
 #include "gg_conv.h"
 #include <stdlib.h>
+#ifndef GG_HALO_WPS
+#define GG_HALO_WPS(NT) 2      /* measured: 4 waves/SIMD forces scratch spills (NT=2) and is not faster */
+#endif
 
 template <int D3, int NT, int UP>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+__global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 4 : 16, TW = 16;
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
+    constexpr int NTHR = 512;
     constexpr int KD = D3 ? 3 : 1;
     constexpr int NTAPS = KD * 9;
     constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1;
@@ -23,14 +27,15 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2;
     constexpr int NROWS = HD * HH * HW;
     constexpr int NPIECE = NROWS * 4;
-    constexpr int JMAX = (NPIECE + 255) / 256;
+    constexpr int JMAX = (NPIECE + NTHR - 1) / NTHR;
     constexpr int XBYTES = ((NROWS * 64 + 1023) / 1024) * 1024;
     constexpr int WBYTES = NT * 2048;                    // one tap: 32*NT cout rows x 64 B
     __shared__ __attribute__((aligned(1024))) char smem[XBYTES + 2 * WBYTES];
     char *xs = smem;
     char *wsm = smem + XBYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: tile rows live in SGPRs
     const int fr = lane & 15, fq = lane >> 4;
 
     // ---- tile coordinates; consecutive (remapped) block ids walk W, then H, then D tiles: neighbours share their halo in L2.
@@ -51,22 +56,19 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
     const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
     const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
 
-    // ---- per-thread staging duties (piece = 16 B = 8 channels; q is the same for all of a thread's pieces)
+    // ---- per-thread staging duties (piece = 16 B = 8 channels; q is the same for all of a thread's pieces).
+    // The source position of piece j is recomputed per chunk (constexpr divisors: a few VALU) instead of pinning JMAX VGPRs.
     const int xq = tid & 3;
-    int soff[JMAX];                  // position index of the piece's row in the source tensor, or -1 (zero padding)
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-        const int i = tid + 256 * j;
+    auto src_pos = [&](int j) -> int {            // position index of the piece's row in the source tensor, -1 = zero padding
+        const int i = tid + NTHR * j;
+        if (i >= NPIECE) return -1;
         const int row = i >> 2;
-        soff[j] = -1;
-        if (i < NPIECE) {
-            const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
-            const int hh = rem / HW, hw = rem - hh * HW;
-            const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-            if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
-                soff[j] = ((n * p.D + id) * p.H + ih) * p.W + iw;
-        }
-    }
+        const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        if (id < 0 || id >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return -1;
+        return ((n * p.D + id) * p.H + ih) * p.W + iw;
+    };
 
     // ---- per-lane activation-operand row offsets: row(tap) = RD(tile,kd) + RH(tile,kh) + rw[kw]; only rw depends on the lane
     int rw[3];
@@ -83,8 +85,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
     auto issue_w = [&](int ks, int buf) {
         const int chunk = ks / NTAPS, tap = ks - chunk * NTAPS;
 #pragma unroll
-        for (int i = 0; i < (NT * 2 + 3) / 4; ++i) {
-            const int piece1k = wave + 4 * i;                   // which 1 KiB piece of the NT*2 KiB tile this wave moves
+        for (int i = 0; i < (NT * 2 + 7) / 8; ++i) {
+            const int piece1k = wave + 8 * i;                   // which 1 KiB piece of the NT*2 KiB tile this wave moves
             if (piece1k < NT * 2) {
                 const int g = piece1k >> 1, half = piece1k & 1;
                 const bf16_t *src = p.weight + ((((long long)(g0 + g) * NTAPS + tap) * p.nchunk + chunk) << 10) + half * 512 + lane * 8;
@@ -104,20 +106,28 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
             const bf16_t *src = second ? p.src2 : p.src1;
             const int Cs = second ? p.C2 : p.C1;
             const int coff = (second ? chunk - p.nchunk1 : chunk) * 32 + xq * 8;
-            u32x4 v[JMAX];
-#pragma unroll
-            for (int j = 0; j < JMAX; ++j) {
-                v[j] = u32x4{0u, 0u, 0u, 0u};
-                if (soff[j] >= 0) v[j] = *reinterpret_cast<const u32x4 *>(src + (long long)soff[j] * Cs + coff);
-            }
+            f32x4 s0, s1, b0, b1;
             if (p.prologue_act) {
                 const long long so = (long long)n * (p.C1 + p.C2) + chunk * 32 + xq * 8;
-                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so), s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so), b1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
+                s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so); s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so + 4);
+                b0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so); b1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
+            }
+            constexpr int JG = 3;                                   // pieces in flight per thread (bounds the VGPR footprint)
+#pragma unroll 1
+            for (int j0 = 0; j0 < JMAX; j0 += JG) {
+                u32x4 v[JG];
+                bool ok[JG];
 #pragma unroll
-                for (int j = 0; j < JMAX; ++j) {
-                    if (soff[j] >= 0) {
-                        bf16x8 xb = __builtin_bit_cast(bf16x8, v[j]);
+                for (int jj = 0; jj < JG; ++jj) {
+                    v[jj] = u32x4{0u, 0u, 0u, 0u};
+                    const int sp = src_pos(j0 + jj);
+                    ok[jj] = sp >= 0;
+                    if (ok[jj]) v[jj] = *reinterpret_cast<const u32x4 *>(src + (long long)sp * Cs + coff);
+                }
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj) {
+                    if (p.prologue_act && ok[jj]) {
+                        bf16x8 xb = __builtin_bit_cast(bf16x8, v[jj]);
                         bf16x8 yb;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -129,16 +139,15 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
                             yb[e] = (bf16_t)y0;
                             yb[e + 4] = (bf16_t)y1;
                         }
-                        v[j] = __builtin_bit_cast(u32x4, yb);
+                        v[jj] = __builtin_bit_cast(u32x4, yb);
+                    }
+                    const int i = tid + NTHR * (j0 + jj);
+                    if (i < NPIECE) {
+                        const int row = i >> 2;
+                        *reinterpret_cast<u32x4 *>(xs + row * 64 + swz64(row, xq) * 16) = v[jj];
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < JMAX; ++j)
-                if (tid + 256 * j < NPIECE) {
-                    const int row = (tid >> 2) + 64 * j;
-                    *reinterpret_cast<u32x4 *>(xs + row * 64 + swz64(row, xq) * 16) = v[j];
-                }
         }
         __syncthreads();          // box visible; (vmcnt(0) inside: the first weight tile of the chunk has landed too)
 
@@ -147,32 +156,34 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
         // ================= 27 (9) taps from LDS =================
 #pragma unroll 1
         for (int kd = 0; kd < KD; ++kd) {
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int tap = kd * 9 + t9;
-                const int ks = chunk * NTAPS + tap;
-                if (ks + 1 < KS) issue_w(ks + 1, (ks + 1) & 1);
-                const int kh = t9 / 3, kw = t9 % 3;
-                const char *wb = wsm + (ks & 1) * WBYTES;
-                bf16x8 xf[4];
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    const int ks = chunk * NTAPS + tap;
+                    if (ks + 1 < KS) issue_w(ks + 1, (ks + 1) & 1);
+                    const char *wb = wsm + (ks & 1) * WBYTES;
+                    bf16x8 xf[4];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                    const int tile = wave * 4 + tt;                 // one W-row of 16 output positions
-                    const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
-                    const int hd = D3 ? (UP ? ((od + kd + 1) >> 1) : od + kd) : 0;
-                    const int hh = UP ? ((oh + kh + 1) >> 1) : oh + kh;
-                    const int row = (hd * HH + hh) * HW + rw[kw];
-                    xf[tt] = *reinterpret_cast<const bf16x8 *>(xs + row * 64 + swz64(row, fq) * 16);
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int tile = wave * 4 + tt;             // one W-row of 16 output positions
+                        const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+                        const int hd = D3 ? (UP ? ((od + kd + 1) >> 1) : od + kd) : 0;
+                        const int hh = UP ? ((oh + kh + 1) >> 1) : oh + kh;
+                        const int row = (hd * HH + hh) * HW + rw[kw];
+                        xf[tt] = *reinterpret_cast<const bf16x8 *>(xs + row * 64 + swz64(row, fq) * 16);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 2 * NT; ++ct) {
+                        const int r = ct * 16 + fr;
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);   // image pre-swizzled at pack time
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt)
+                            acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[tt], acc[tt][ct], 0, 0, 0);
+                    }
+                    __syncthreads();  // next tap's weights landed (vmcnt(0)); this tap's slot / the box may be overwritten
                 }
-#pragma unroll
-                for (int ct = 0; ct < 2 * NT; ++ct) {
-                    const int r = ct * 16 + fr;
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);   // image pre-swizzled at pack time
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[tt], acc[tt][ct], 0, 0, 0);
-                }
-                __syncthreads();      // next tap's weights landed (vmcnt(0)); this tap's slot / the box may be overwritten
             }
         }
     }
@@ -213,10 +224,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p, cons
 template <int D3, int NT, int UP>
 static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 4 : 16, TW = 16;
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(256), 0, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(512), 0, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -240,11 +251,20 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (!(p.kh == 3 && p.kw == 3 && (p.kd == 3 || p.kd == 1))) return GG_ERR_UNSUPPORTED;
     if (p.stride != 1 || p.pad != 1) return GG_ERR_UNSUPPORTED;
     if (!d3 && p.D != 1) return GG_ERR_UNSUPPORTED;
-    const int TD = d3 ? 4 : 1, TH = d3 ? 4 : 16, TW = 16;
+    const int TD = d3 ? 4 : 1, TH = d3 ? 8 : 32, TW = 16;
     if (p.Wo % TW || p.Ho % TH || p.Do % TD) return GG_ERR_UNSUPPORTED;
     const int G = p.Cout_pad / 32;
-    const int NT = (G % 4 == 0) ? 4 : (G % 3 == 0) ? 3 : (G % 2 == 0) ? 2 : 1;
-    const long long blocks = (long long)p.N * (p.Do / TD) * (p.Ho / TH) * (p.Wo / TW) * (G / NT);
+    const long long tiles = (long long)p.N * (p.Do / TD) * (p.Ho / TH) * (p.Wo / TW);
+    // widest cout tile (fewest re-stagings of the box) that still gives >= 256 workgroups; else the widest with >= 128
+    static const int max_nt = [] { const char *e = getenv("GG_HALO_MAX_NT"); return e ? atoi(e) : 4; }();
+    int NT = 0;
+    for (int want : {256, 128}) {
+        for (int cand : {4, 3, 2, 1})
+            if (cand <= max_nt && G % cand == 0 && tiles * (G / cand) >= want) { NT = cand; break; }
+        if (NT) break;
+    }
+    if (!NT) NT = 1;
+    const long long blocks = tiles * (G / NT);
     static const long long min_blocks = [] { const char *e = getenv("GG_HALO_MIN_BLOCKS"); return e ? atoll(e) : 128LL; }();
     if (blocks < min_blocks) return GG_ERR_UNSUPPORTED;    // under-filled grid: split-K gather path is faster
     if (stream == (hipStream_t)-1) return GG_OK;
