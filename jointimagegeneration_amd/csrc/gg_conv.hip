@@ -13,6 +13,7 @@
 //                  swizzled, double-buffered LDS tile.
 //   conv_halo    : fast path for 3x3(x3) stride-1 convs on large extents (see gg_conv_halo.hip).
 #include "gg_conv.h"
+#include <stdlib.h>
 
 template <int NT, int PF>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
@@ -341,12 +342,14 @@ static GatherPlan plan_gather(long long M, int Cout_pad, int KS)
     int NT = (G % 4 == 0) ? 4 : (G % 5 == 0) ? 5 : (G % 3 == 0) ? 3 : (G % 2 == 0) ? 2 : 1;
     const long long mb = (M + 127) / 128;
     int splitk = 1;
+    static const int k_target = [] { const char *e = getenv("GG_SPLITK_TARGET"); return e ? atoi(e) : 512; }();
+    static const int k_minsteps = [] { const char *e = getenv("GG_SPLITK_MINSTEPS"); return e ? atoi(e) : 8; }();
     if (mb * (G / NT) < 192) {
         if (G % 2 == 0 && NT > 2 && mb * (G / 2) <= 1024) NT = 2;
         if (mb * (G / NT) < 192 && NT > 1) NT = 1;
         long long blocks = mb * (G / NT);
-        long long want = (512 + blocks - 1) / blocks;
-        long long maxs = KS / 8 > 0 ? KS / 8 : 1;
+        long long want = (k_target + blocks - 1) / blocks;
+        long long maxs = KS / k_minsteps > 0 ? KS / k_minsteps : 1;
         splitk = (int)(want < maxs ? want : maxs);
         if (splitk < 1) splitk = 1;
         if (splitk > 64) splitk = 64;

@@ -16,10 +16,14 @@
 #endif
 
 template <int D3, int NT, int UP>
-__global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+__global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
     constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
-    constexpr int NTHR = 512;
+    // NT <= 2: 4 waves x 8 position-tiles (128 pos x 32*NT couts per wave, 2 workgroups per CU overlap staging and MFMA);
+    // NT >= 3: 8 waves x 4 position-tiles (the accumulator would not fit otherwise)
+    constexpr int NWAVE = NT <= 2 ? 4 : 8;
+    constexpr int TPW = 32 / NWAVE;
+    constexpr int NTHR = NWAVE * 64;
     constexpr int KD = D3 ? 3 : 1;
     constexpr int NTAPS = KD * 9;
     constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1;
@@ -75,9 +79,9 @@ __global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const C
 #pragma unroll
     for (int k = 0; k < 3; ++k) rw[k] = UP ? ((fr + k + 1) >> 1) : (fr + k);
 
-    f32x4 acc[4][2 * NT];
+    f32x4 acc[TPW][2 * NT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int b = 0; b < 2 * NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const C
     auto issue_w = [&](int ks, int buf) {
         const int chunk = ks / NTAPS, tap = ks - chunk * NTAPS;
 #pragma unroll
-        for (int i = 0; i < (NT * 2 + 7) / 8; ++i) {
-            const int piece1k = wave + 8 * i;                   // which 1 KiB piece of the NT*2 KiB tile this wave moves
+        for (int i = 0; i < (NT * 2 + NWAVE - 1) / NWAVE; ++i) {
+            const int piece1k = wave + NWAVE * i;                   // which 1 KiB piece of the NT*2 KiB tile this wave moves
             if (piece1k < NT * 2) {
                 const int g = piece1k >> 1, half = piece1k & 1;
                 const bf16_t *src = p.weight + ((((long long)(g0 + g) * NTAPS + tap) * p.nchunk + chunk) << 10) + half * 512 + lane * 8;
@@ -164,10 +168,10 @@ __global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const C
                     const int ks = chunk * NTAPS + tap;
                     if (ks + 1 < KS) issue_w(ks + 1, (ks + 1) & 1);
                     const char *wb = wsm + (ks & 1) * WBYTES;
-                    bf16x8 xf[4];
+                    bf16x8 xf[TPW];
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) {
-                        const int tile = wave * 4 + tt;             // one W-row of 16 output positions
+                    for (int tt = 0; tt < TPW; ++tt) {
+                        const int tile = wave * TPW + tt;             // one W-row of 16 output positions
                         const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
                         const int hd = D3 ? (UP ? ((od + kd + 1) >> 1) : od + kd) : 0;
                         const int hh = UP ? ((oh + kh + 1) >> 1) : oh + kh;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const C
                         const int r = ct * 16 + fr;
                         const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);   // image pre-swizzled at pack time
 #pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
+                        for (int tt = 0; tt < TPW; ++tt)
                             acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[tt], acc[tt][ct], 0, 0, 0);
                     }
                     __syncthreads();  // next tap's weights landed (vmcnt(0)); this tap's slot / the box may be overwritten
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(512, GG_HALO_WPS(NT)) void conv_halo_kernel(const C
     // ================= epilogue: + bias[n] (+ residual) -> bf16 / fp32 =================
     const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int tile = wave * 4 + tt;
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int tile = wave * TPW + tt;
         const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
         const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
 #pragma unroll
@@ -227,7 +231,7 @@ static int launch_halo(const ConvParams &p, hipStream_t stream)
     constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(512), 0, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(NT <= 2 ? 256 : 512), 0, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
