@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--ccdm-steps", type=int, default=250, help="CCDM reverse steps (250 = params_eval.yml time_steps)")
     ap.add_argument("--slices", type=int, default=256)
+    ap.add_argument("--volumes-per-gpu", type=int, default=1, help="independent volumes sampled concurrently per GPU (BASELINE C5 = 1)")
     ap.add_argument("--max-slices", type=int, default=None, help="DEV ONLY: truncate the slice loop (marks the line partial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -142,14 +143,15 @@ def main():
     if os.environ.get("GG_NO_GRAPH") == "1":          # profiling aid: rocprofv3 --kernel-trace aborts on long hipGraph replays
         pipe.ccdm.use_graph = False
         pipe.sampler.use_graph = False
+        pipe.use_graph = False
     log("models ready; untimed warm-up (weight repack, hipGraph capture)")
 
     def one_volume(i):
-        return pipe.run_volume(N=1, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=1024 + rank + 1000 * i,
+        return pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=1024 + rank + 1000 * i,
                                max_slices=args.max_slices)
 
     # untimed: weight repack + graph capture warm-up on the real shapes (2 short chains), then W full warm-up steps
-    pipe.run_volume(N=1, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=7, ccdm_init_t=10005, max_slices=2)
+    pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=7, ccdm_init_t=10005, max_slices=3)
     for i in range(args.warmup):
         one_volume(-1 - i)
 
@@ -160,11 +162,11 @@ def main():
         partial = args.max_slices is not None or args.ccdm_steps != 250 or args.slices != 256
         line = {
             "metric": "sampled voxels/sec @50 DDIM steps, 128^3 mask + 512^2x256 CT",
-            "value": round(world * args.steps * VOXELS_PER_VOLUME / elapsed, 1), "unit": "voxels/s",
+            "value": round(world * args.steps * args.volumes_per_gpu * VOXELS_PER_VOLUME / elapsed, 1), "unit": "voxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "C5 full GuideGen volume per GPU: CCDM 128^3 K=14 250 steps -> LDM 256 slices x (cond-encode + 50 DDIM @4x64x64 + AE decode 512^2)",
-                       "volumes_per_gpu_per_step": 1, "ccdm_steps": args.ccdm_steps, "ddim_steps": 50, "slices": args.slices,
+                       "volumes_per_gpu_per_step": args.volumes_per_gpu, "ccdm_steps": args.ccdm_steps, "ddim_steps": 50, "slices": args.slices,
                        "parallelism": f"replicas x{world} (one volume per GPU, no collective)", "weights": "random-init (seed recipe)"},
         }
         if partial:

@@ -15,7 +15,7 @@
 #include "gg_conv.h"
 #include <stdlib.h>
 
-template <int NT, int PF>
+template <int NT, int PF, int PRO>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
 {
     constexpr int BM = 128;
@@ -31,36 +31,43 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     const long long m0 = (long long)blockIdx.x * BM;
     const int g0 = blockIdx.y * NT;
 
-    // ---- per-thread gather duties: rows r and r+64, 16-byte piece q of the 64-byte channel chunk
+    // ---- per-thread gather duties: rows r and r+64, 16-byte piece q of the 64-byte channel chunk.
+    // All per-k-step address arithmetic is 32-bit (in-sample element offsets); the 64-bit part is a per-row sample base.
     const int xq = tid & 3;
     int bn[2], bd[2], bh[2], bw[2];
     bool rv[2];
-    const long long osp = (long long)p.Do * p.Ho * p.Wo;
+    const bf16_t *rb1[2], *rb2[2];
+    const unsigned osp = (unsigned)(p.Do * p.Ho * p.Wo);
+    const unsigned ohw = (unsigned)(p.Ho * p.Wo);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         long long m = m0 + (tid >> 2) + 64 * i;
         rv[i] = m < p.M;
-        if (!rv[i]) m = 0;
-        int n = (int)(m / osp);
-        long long r = m - (long long)n * osp;
-        int od = (int)(r / ((long long)p.Ho * p.Wo));
-        r -= (long long)od * p.Ho * p.Wo;
-        int oh = (int)(r / p.Wo);
-        int ow = (int)(r - (long long)oh * p.Wo);
-        bn[i] = n;
+        unsigned mu = rv[i] ? (unsigned)m : 0u;              // host guarantees M < 2^31
+        unsigned n = mu / osp;
+        unsigned r = mu - n * osp;
+        unsigned od = r / ohw;
+        r -= od * ohw;
+        unsigned oh = r / (unsigned)p.Wo;
+        unsigned ow = r - oh * (unsigned)p.Wo;
+        bn[i] = (int)n;
         // coordinates in the (possibly upsampled) input frame of tap (0,0,0)
-        bd[i] = (p.kd == 1) ? od * (p.upsample ? 1 : p.stride) : od * p.stride - p.pad;
-        bh[i] = (p.kh == 1) ? oh * (p.upsample ? 1 : p.stride) : oh * p.stride - p.pad;
-        bw[i] = (p.kw == 1) ? ow * (p.upsample ? 1 : p.stride) : ow * p.stride - p.pad;
+        bd[i] = (p.kd == 1) ? (int)od * p.stride : (int)od * p.stride - p.pad;
+        bh[i] = (p.kh == 1) ? (int)oh * p.stride : (int)oh * p.stride - p.pad;
+        bw[i] = (p.kw == 1) ? (int)ow * p.stride : (int)ow * p.stride - p.pad;
+        const long long sp = (long long)p.D * p.H * p.W;
+        rb1[i] = p.src1 + (long long)n * sp * p.C1 + xq * 8;
+        rb2[i] = p.src2 ? p.src2 + (long long)n * sp * p.C2 + xq * 8 : nullptr;
     }
     const int upD = (p.upsample && p.kd == 3) ? 1 : 0;  // 2-D convs never upsample the dummy D axis
     const int upHW = p.upsample ? 1 : 0;
-    const int limD = p.D << upD, limH = p.H << upHW, limW = p.W << upHW;
+    const unsigned limD = (unsigned)(p.D << upD), limH = (unsigned)(p.H << upHW), limW = (unsigned)(p.W << upHW);
+    const int gnC = p.C1 + p.C2;
 
     // register prefetch ring: PF k-steps of global loads are in flight (the loop is otherwise one load latency per k-step)
     u32x4 xreg[PF][2];
     u32x4 wreg[PF][WITER];
-    long long xso[PF][2];       // GroupNorm scale/shift offset of the piece, -1: padding / out of range (stays zero)
+    int xso[PF][2];             // GroupNorm scale/shift offset of the piece, -1: padding / out of range (stays zero)
 
     // split-K: blockIdx.z owns k-steps [ks_begin, ks_end) of the (chunk outer, tap inner) sequence
     const int KS_all = p.ntaps * p.nchunk;
@@ -69,53 +76,55 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     int chunk = ks_begin / p.ntaps, tap = ks_begin - (ks_begin / p.ntaps) * p.ntaps;   // counters for the NEXT global load
     int tkd = tap / (p.kh * p.kw), tkh = (tap / p.kw) % p.kh, tkw = tap % p.kw;
 
-    auto load_regs = [&](u32x4 (&xr)[2], u32x4 (&wr)[WITER], long long (&so)[2]) {
+    // weight tile offset advances incrementally with the (chunk outer, tap inner) walk
+    long long woff = ((((long long)g0 * p.ntaps + tap) * p.nchunk + chunk) << 10);
+    const long long wstep_tap = (long long)p.nchunk << 10;
+    const long long wstep_wrap = (1LL << 10) - (long long)p.ntaps * wstep_tap;          // tap wraps to 0, chunk + 1
+    const long long wgroup = ((long long)p.ntaps * p.nchunk) << 10;
+
+    auto load_regs = [&](u32x4 (&xr)[2], u32x4 (&wr)[WITER], int (&so)[2]) {
         const bool second = chunk >= p.nchunk1;
-        const bf16_t *src = second ? p.src2 : p.src1;
         const int Cs = second ? p.C2 : p.C1;
-        const int cc = second ? chunk - p.nchunk1 : chunk;
+        const int coff = (second ? chunk - p.nchunk1 : chunk) * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int ud = bd[i] + tkd, uh = bh[i] + tkh, uw = bw[i] + tkw;
-            bool ok = rv[i] && ud >= 0 && ud < limD && uh >= 0 && uh < limH && uw >= 0 && uw < limW;
+            const unsigned ud = (unsigned)(bd[i] + tkd), uh = (unsigned)(bh[i] + tkh), uw = (unsigned)(bw[i] + tkw);
+            const bool ok = rv[i] && ud < limD && uh < limH && uw < limW;         // unsigned compare also rejects negatives
             u32x4 v = {0u, 0u, 0u, 0u};
             so[i] = -1;
             if (ok) {
-                int id = ud >> upD, ih = uh >> upHW, iw = uw >> upHW;
-                long long off = ((((long long)bn[i] * p.D + id) * p.H + ih) * p.W + iw) * Cs + cc * 32 + xq * 8;
-                v = *reinterpret_cast<const u32x4 *>(src + off);
-                so[i] = (long long)bn[i] * (p.C1 + p.C2) + chunk * 32 + xq * 8;
+                const unsigned pos = (((ud >> upD) * (unsigned)p.H + (uh >> upHW)) * (unsigned)p.W + (uw >> upHW));
+                const bf16_t *base = second ? rb2[i] : rb1[i];
+                v = *reinterpret_cast<const u32x4 *>(base + (pos * (unsigned)Cs + (unsigned)coff));
+                so[i] = bn[i] * gnC + chunk * 32 + xq * 8;
             }
             xr[i] = v;
         }
 #pragma unroll
         for (int j = 0; j < WITER; ++j) {
             int i = tid + 256 * j;
-            if (i < NT * 128) {
-                int g = i >> 7, pc = i & 127;
-                long long off = ((((long long)(g0 + g) * p.ntaps + tap) * p.nchunk + chunk) << 10) + pc * 8;
-                wr[j] = *reinterpret_cast<const u32x4 *>(p.weight + off);
-            }
+            if (i < NT * 128) wr[j] = *reinterpret_cast<const u32x4 *>(p.weight + woff + (long long)(i >> 7) * wgroup + (i & 127) * 8);
         }
         // advance (chunk outer, tap inner)
         ++tap;
+        woff += wstep_tap;
         if (++tkw == p.kw) {
             tkw = 0;
             if (++tkh == p.kh) {
                 tkh = 0;
-                if (++tkd == p.kd) { tkd = 0; tap = 0; ++chunk; }
+                if (++tkd == p.kd) { tkd = 0; tap = 0; ++chunk; woff += wstep_wrap; }
             }
         }
     };
 
-    auto write_lds = [&](int buf, u32x4 (&xr)[2], u32x4 (&wr)[WITER], long long (&so)[2]) {
+    auto write_lds = [&](int buf, u32x4 (&xr)[2], u32x4 (&wr)[WITER], int (&so)[2]) {
         char *xb = smem + buf * STAGE;
         char *wb = xb + XBYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int r = (tid >> 2) + 64 * i;
             u32x4 v = xr[i];
-            if (p.prologue_act && so[i] >= 0) {   // fused GroupNorm(*SiLU): y = act(x*scale + shift); zero padding stays zero
+            if (PRO && so[i] >= 0) {   // fused GroupNorm(*SiLU): y = act(x*scale + shift); zero padding stays zero
                 f32x4 s0 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so[i]);
                 f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.gn_scale + so[i] + 4);
                 f32x4 h0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so[i]);
@@ -125,7 +134,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float y0 = (float)xb8[j] * s0[j] + h0[j], y1 = (float)xb8[j + 4] * s1[j] + h1[j];
-                    if (p.prologue_act == 1) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
+                    if (p.prologue_act == 1) {
+                        y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                        y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                    }
                     yb[j] = (bf16_t)y0;
                     yb[j + 4] = (bf16_t)y1;
                 }
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     for (int pt = 0; pt < 2; ++pt) {
         long long m = m0 + wave * 32 + pt * 16 + fr;
         if (m >= p.M) continue;
-        int n = (int)(m / osp);
+        int n = (int)((unsigned)m / osp);
         const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
 #pragma unroll
         for (int ct = 0; ct < 2 * NT; ++ct) {
@@ -320,7 +332,10 @@ template <int NT>
 static int launch_gather(const ConvParams &p, hipStream_t stream)
 {
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)(p.Cout_pad / (32 * NT)), (unsigned)p.splitk);
-    hipLaunchKernelGGL((conv_gather_kernel<NT, (NT <= 2 ? 4 : 2)>), grid, dim3(256), 0, stream, p);
+    if (p.prologue_act)
+        hipLaunchKernelGGL((conv_gather_kernel<NT, (NT <= 2 ? 4 : 2), 1>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_gather_kernel<NT, (NT <= 2 ? 4 : 2), 0>), grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
     if (p.splitk > 1) {
         long long total = p.M * (p.Cout_pad / 4);
@@ -417,6 +432,8 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
 
     ConvParams p;
     fill_params(d, p);
+    if (p.M >= (1LL << 31) || (long long)d->D * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1LL << 31))
+        GG_FAIL(GG_ERR_UNSUPPORTED, "conv: tensor too large for 32-bit in-sample offsets");
 
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;

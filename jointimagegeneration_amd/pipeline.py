@@ -64,6 +64,8 @@ class GuideGenPipeline:
         self.sampler = DDIMSampler(ldm)
         self.sampler.make_schedule(ddim_steps, ddim_eta=0.0, verbose=False)
         self.stats: Dict[str, float] = {}
+        self.use_graph = True
+        self._slice_graphs: Dict = {}
 
     # ---- stage 1 ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -89,7 +91,6 @@ class GuideGenPipeline:
         Cz = ldm.channels
         g = torch.Generator(device=dev).manual_seed(seed)
         samples = torch.zeros((depth, N, hw, hw), dtype=torch.float32, device=dev)        # slice-major: one slice is contiguous
-        cond_in = torch.empty((N, 1, hw, hw, 32), dtype=torch.bfloat16, device=dev)
         # slices whose upsampled mask is non-empty (sample_diffusion.py:202); python indexing of the reference loop kept
         Dm = labels.shape[1]
         nz = (labels != 0).flatten(2).any(-1).any(0)                                       # [Dm]
@@ -99,6 +100,26 @@ class GuideGenPipeline:
         todo = list(range(start - 1, end + 1))
         if max_slices is not None:
             todo = todo[:max_slices]
+        # static buffers + hipGraphs for the two per-slice networks (cond-stage encode, first-stage decode)
+        key = (N, hw, str(dev))
+        sg = self._slice_graphs.get(key)
+        if sg is None:
+            sg = dict(cond_in=torch.empty((N, 1, hw, hw, 32), dtype=torch.bfloat16, device=dev),
+                      z=torch.zeros((N, 1, lat, lat, 32), dtype=torch.bfloat16, device=dev),
+                      ds=torch.empty((N, hw, hw), dtype=torch.float32, device=dev), enc=None, dec=None, mom=None, warmed=False)
+            self._slice_graphs[key] = sg
+        cond_in, zbuf = sg["cond_in"], sg["z"]
+
+        def encode():
+            sg["mom"] = ldm.cond_stage_model.encode_moments_cl(CL(cond_in, 2))         # fp32 CL [N,1,lat,lat,32]; mode() = mean
+            st["unet_in"][..., Cz:2 * Cz].copy_(sg["mom"].t[..., :Cz])                # c_concat = posterior mean (plumbing copy)
+
+        def decode():
+            zbuf[..., :Cz].copy_(st["x"] * (1.0 / ldm.scale_factor))
+            dec = ldm.first_stage_model.decode_cl(CL(zbuf, Cz))                        # fp32 CL [N,1,hw,hw,32]
+            sg["ds"].copy_(dec.t[..., 0].reshape(N, hw, hw))
+            ops.minmax_normalise(sg["ds"], out=sg["ds"])
+
         t_last = time.time()
         for it, m in enumerate(todo):
             if time.time() - t_last > self.progress_every_s:
@@ -107,17 +128,32 @@ class GuideGenPipeline:
             mm = m % depth
             prev = samples[max(0, m - 1) % depth]
             ops.mask_to_cond_slice(labels, mm, depth, hw, hw, prev, cond_in)
-            mom = ldm.cond_stage_model.encode_moments_cl(CL(cond_in, 2))                   # fp32 CL [N,1,lat,lat,32]; mode() = mean
             x_T = torch.randn((N, 1, lat, lat, Cz), generator=g, device=dev)
             st["x"].copy_(x_T)
-            st["unet_in"][..., :Cz].copy_(x_T)                                             # plumbing: fp32 -> bf16 copy of x_T
-            st["unet_in"][..., Cz:2 * Cz].copy_(mom.t[..., :Cz])                          # c_concat = posterior mean
+            st["unet_in"][..., :Cz].copy_(x_T)                                         # plumbing: fp32 -> bf16 copy of x_T
+            if not self.use_graph:
+                encode()
+            elif not sg["warmed"]:
+                encode()                                                               # eager once: fills the repack cache
+            else:
+                if sg["enc"] is None:
+                    sg["enc"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(sg["enc"]):
+                        encode()
+                sg["enc"].replay()
             sampler.run_steps(st, None, 0.0, None)
-            z = torch.zeros((N, 1, lat, lat, 32), dtype=torch.bfloat16, device=dev)
-            z[..., :Cz].copy_(st["x"] * (1.0 / ldm.scale_factor))
-            dec = ldm.first_stage_model.decode_cl(CL(z, Cz))                               # fp32 CL [N,1,hw,hw,32]
-            ds = dec.t[..., 0].reshape(N, hw, hw).contiguous()
-            ops.minmax_normalise(ds, out=samples[mm])
+            if not self.use_graph:
+                decode()
+            elif not sg["warmed"]:
+                decode()
+                sg["warmed"] = True
+            else:
+                if sg["dec"] is None:
+                    sg["dec"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(sg["dec"]):
+                        decode()
+                sg["dec"].replay()
+            samples[mm].copy_(sg["ds"])
         return samples.permute(1, 0, 2, 3)
 
     @torch.no_grad()
