@@ -76,6 +76,9 @@ typedef struct {
     const float *gn_shift;
     void *workspace;           /* caller-owned scratch (split-K slabs); size from gg_conv_workspace_bytes */
     int64_t workspace_bytes;
+    int32_t *tile_counters;    /* optional, >= 65536 int32, ZERO on entry and left zero on exit, used by one stream at a time:
+                                  enables the in-launch split-K combine (last-arriving K slice reduces + runs the epilogue);
+                                  NULL = separate deterministic reduce launch. Results are bit-identical either way. */
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */

@@ -13,6 +13,7 @@ struct ConvParams {
     const float *bias, *gn_scale, *gn_shift;
     void *out;
     float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
+    int *counters;            // per output tile arrival tickets (zero on entry, zero on exit) or nullptr
     int splitk;
 };
 

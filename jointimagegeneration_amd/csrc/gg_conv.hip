@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         }
     }
 
-    if (p.splitk > 1) {   // raw fp32 partial tile -> slab; bias/residual/cast happen in conv_splitk_reduce_kernel
+    if (p.splitk > 1) {
+        // raw fp32 partial tile -> this block's slab
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             long long m = m0 + wave * 32 + pt * 16 + fr;
@@ -205,6 +206,59 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
             for (int ct = 0; ct < 2 * NT; ++ct) {
                 int co = (g0 * 32) + ct * 16 + fq * 4;
                 *reinterpret_cast<f32x4 *>(p.ws + ((long long)blockIdx.z * p.M + m) * p.Cout_pad + co) = acc[pt][ct];
+            }
+        }
+        if (!p.counters) return;          // combine + epilogue in conv_splitk_reduce_kernel
+        // ---- in-launch combine by the LAST arriving K-slice of this output tile (placement-independent protocol:
+        // plain slab stores -> every wave drains -> barrier -> lane 0: agent release, drain, relaxed agent ticket;
+        // last arriver: agent acquire, drain, barrier, plain loads).  cdna_hip_programming.md 5 "In-launch split-K reduction".
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(smem);                  // all LDS reads of the k-loop are behind the barrier above
+        int *cnt = p.counters + (blockIdx.y * gridDim.x + blockIdx.x);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (ticket == p.splitk - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // leave the ticket zero for the next launch
+        }
+        __syncthreads();
+        // fixed z order: bit-identical to the separate reduce kernel, independent of arrival order
+        constexpr int Q4 = NT * 8;                                   // float4 per tile row
+        for (int i = tid; i < 128 * Q4; i += 256) {
+            const int row = i / Q4, c4 = i - row * Q4;
+            const long long m = m0 + row;
+            if (m >= p.M) continue;
+            const int co = g0 * 32 + c4 * 4;
+            const long long o = m * p.Cout_pad + co;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(p.ws + o);
+            for (int z = 1; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(p.ws + (long long)z * p.M * p.Cout_pad + o);
+            if (p.bias) {
+                const int n = (int)((unsigned)m / osp);
+                v += *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co);
+            }
+            if (p.residual) {
+                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co + j >= p.Cout) v[j] = 0.f;
+            if (p.out_dtype == GG_F32) {
+                *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+            } else {
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
             }
         }
         return;
@@ -337,7 +391,7 @@ static int launch_gather(const ConvParams &p, hipStream_t stream)
     else
         hipLaunchKernelGGL((conv_gather_kernel<NT, (NT <= 2 ? 4 : 2), 0>), grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && !p.counters) {
         long long total = p.M * (p.Cout_pad / 4);
         long long blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
@@ -393,6 +447,7 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.residual = (const bf16_t *)d->residual; p.bias = d->bias; p.gn_scale = d->gn_scale; p.gn_shift = d->gn_shift;
     p.out = d->out;
     p.ws = nullptr;
+    p.counters = nullptr;
     p.splitk = 1;
 }
 
@@ -445,6 +500,8 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
             GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "conv: split-K needs %lld workspace bytes (gg_conv_workspace_bytes), got %lld", need, (long long)d->workspace_bytes);
         p.ws = (float *)d->workspace;
         p.splitk = pl.splitk;
+        const long long tiles = ((p.M + 127) / 128) * (p.Cout_pad / (32 * pl.NT));
+        p.counters = tiles <= 65536 ? (int *)d->tile_counters : nullptr;
     }
     switch (pl.NT) {
         case 5: return launch_gather<5>(p, stream);

@@ -119,12 +119,23 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     const bf16_t *b1 = s1 + (long long)n * S * C1;
     const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
     float a = 0.f, b = 0.f;
-    for (long long i = tid; i < total; i += 256) {
-        long long r = i / cpg;
-        int c = g * cpg + (int)(i - r * cpg);
-        float v = (c < C1) ? (float)b1[r * C1 + c] : (float)b2[r * C2 + (c - C1)];
-        a += v;
-        b += v * v;
+    // 16-byte loads: the group's channels [c_lo, c_hi) live in pieces p_lo..p_hi of a row; lanes mask the foreign channels
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int p_lo = c_lo >> 3, p_hi = (c_hi - 1) >> 3;
+    const int np = p_hi - p_lo + 1;
+    const long long work = S * np;
+    for (long long i = tid; i < work; i += 256) {
+        const long long r = i / np;
+        const int c0 = (p_lo + (int)(i - r * np)) * 8;
+        const bf16_t *src = (c0 < C1) ? b1 + r * C1 + c0 : b2 + r * C2 + (c0 - C1);
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float f = (c >= c_lo && c < c_hi) ? (float)v[j] : 0.f;
+            a += f;
+            b += f * f;
+        }
     }
     __shared__ double ra[256], rb[256];
     ra[tid] = (double)a;
