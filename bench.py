@@ -43,9 +43,11 @@ def parse():
 
 
 def conv_roofline(pipe, device):
-    """Dominant kernel = the 3-D implicit-GEMM conv of the CCDM UNet (99.3 % of its FLOPs).
-    One eager 128^3 UNet forward with a HIP event pair around EVERY 3-D conv launch on the stream the kernels are
-    launched on; achieved = sum(algorithmic conv FLOPs) / sum(kernel time)."""
+    """Dominant kernel = the 3-D halo-tile implicit-GEMM conv (`conv_halo_kernel<1,NT,UP>`) of the CCDM UNet
+    (3x3x3 convs are 99.3 % of the UNet's FLOPs; the halo kernel runs all of them at the 128^3..32^3 levels).
+    One eager 128^3 UNet forward with a HIP event pair around EVERY conv launch, recorded on the stream the kernels are
+    launched on; achieved = sum(algorithmic FLOPs of the halo launches) / sum(their durations).  The rocprofv3 average of
+    the same kernel name (profiles/) must agree with avg_launch_ms.  traffic: PMC passes parsed by tools/pmc_parse.py."""
     from jointimagegeneration_amd import ops
     from jointimagegeneration_amd.ops import CL
     unet = pipe.ccdm.unet
@@ -58,30 +60,37 @@ def conv_roofline(pipe, device):
     real_conv = ops.conv
 
     def timed_conv(src1, weight, bias, cout, k=(1, 3, 3), stride=1, pad=1, upsample=False, src2=None, **kw):
+        halo = ops.conv_fuses_prologue(src1, cout, k=k, stride=stride, pad=pad, upsample=upsample, src2=src2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = real_conv(src1, weight, bias, cout, k=k, stride=stride, pad=pad, upsample=upsample, src2=src2, **kw)
         e1.record()
         cin = src1.C + (src2.C if src2 is not None else 0)
         M = out.t.shape[0] * out.t.shape[1] * out.t.shape[2] * out.t.shape[3]
-        records.append((e0, e1, 2.0 * M * cout * cin * k[0] * k[1] * k[2], k))
+        records.append((e0, e1, 2.0 * M * cout * cin * k[0] * k[1] * k[2], k, halo))
         return out
 
     ops.conv = timed_conv
-    import jointimagegeneration_amd.blocks as B
-    import jointimagegeneration_amd.unet as U
     try:
         unet.forward_cl(x, row)
         torch.cuda.synchronize()
     finally:
         ops.conv = real_conv
-    k3 = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, k in records if k[0] * k[1] * k[2] == 27]
-    t = sum(a for a, _ in k3)
-    fl = sum(b for _, b in k3)
+    halo = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, k, h in records if h and k[0] == 3]
+    k27 = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, k, h in records if k[0] * k[1] * k[2] == 27]
+    t, fl = sum(a for a, _ in halo), sum(b for _, b in halo)
+    t27, fl27 = sum(a for a, _ in k27), sum(b for _, b in k27)
     ach = fl / t / 1e12
-    return {"bound": "mfma", "kernel": "conv3d implicit-GEMM (3x3x3) of the CCDM UNet @128^3", "achieved": round(ach, 1),
-            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launches": len(k3), "avg_launch_ms": round(t / len(k3) * 1e3, 4), "flops_per_forward": fl}
+    out = {"bound": "mfma", "kernel": "conv_halo_kernel<3-D> (3x3x3 implicit GEMM, halo tile) in one CCDM UNet forward @128^3",
+           "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+           "traffic": None, "launches": len(halo), "avg_launch_ms": round(t / len(halo) * 1e3, 4), "flops_per_launch": round(fl / len(halo)),
+           "all_3x3x3_convs": {"launches": len(k27), "achieved": round(fl27 / t27 / 1e12, 1), "flops_per_forward": fl27}}
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv3d.json")
+    if os.path.exists(pmc):
+        j = json.load(open(pmc))
+        out["traffic"] = j["traffic_bytes_per_launch"]
+        out["traffic_source"] = "profiles/r01_pmc_conv3d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+    return out
 
 
 def cpu_baseline():

@@ -23,7 +23,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <int CH>
 __device__ __forceinline__ int swz_row(int row, int chunk)
 {
-    if constexpr (CH == 4) return chunk ^ ((0 - (row >> 2)) & 3);
+    if constexpr (CH == 4) return chunk ^ ((row >> 1) & 2);
     else if constexpr (CH == 8) return chunk ^ ((row >> 1) & 7);
     else return chunk ^ (row & 15);
 }

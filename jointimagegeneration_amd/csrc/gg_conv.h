@@ -17,7 +17,9 @@ struct ConvParams {
     int splitk;
 };
 
-// 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = l&15, chunk = l>>4):
-// conflict-free for 16 consecutive rows (derivation in DESIGN.md, "LDS images").
-__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
+// 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = r0 + (l&15), chunk = l>>4).
+// chunk ^ ((row>>1)&2) puts the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) on 16
+// distinct 16-byte slots of the 256-byte bank row for EVERY start row r0 (exhaustive search over r0 = 0..15):
+// the shifted reads of the conv taps (row offsets +1, +18, +180) stay conflict-free, not only the aligned ones.
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 1) & 2); }
 
