@@ -183,6 +183,11 @@ int gg_labels_to_onehot(const int32_t *labels, int64_t M, int32_t K, void *oneho
 int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev,
                  int64_t M, int32_t C, float *pred_x0_out, void *unet_in, int32_t unet_in_stride, void *stream);
 
+/* PLMS multistep combination of noise estimates (ldm/models/diffusion/plms.py:218-232), fp32, evaluated left to right:
+ *   out = (c0*e0 + c1*e1 + c2*e2 + c3*e3) / denom ; e1..e3 may be NULL (skipped). */
+int gg_lincomb4(const float *e0, const float *e1, const float *e2, const float *e3, float c0, float c1, float c2, float c3,
+                float denom, int64_t n, float *out, void *stream);
+
 /* Slice normalisation (ds - min)/(max - min) over the whole tensor (latentdiffusion/sample_diffusion.py:222).
  * workspace: >= 2 floats, zero-initialised by the call. */
 int gg_minmax_normalise(const float *src, int64_t n, float *dst, float *workspace2, void *stream);

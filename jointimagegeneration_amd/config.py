@@ -22,6 +22,7 @@ TARGET_ALIASES = {
     "ldm.models.diffusion.ddpm.LatentDiffusion": "jointimagegeneration_amd.ldm.LatentDiffusion",
     "ldm.modules.encoders.modules.IdentityEncoder": "jointimagegeneration_amd.ldm.IdentityEncoder",
     "ldm.models.diffusion.ddim.DDIMSampler": "jointimagegeneration_amd.ldm.DDIMSampler",
+    "ldm.models.diffusion.plms.PLMSSampler": "jointimagegeneration_amd.ldm.PLMSSampler",
     "torch.nn.Identity": "torch.nn.Identity",
 }
 

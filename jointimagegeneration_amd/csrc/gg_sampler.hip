@@ -220,6 +220,37 @@ extern "C" int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// PLMS noise-estimate combination (ldm/models/diffusion/plms.py:218-232), fp32, same left-to-right order as the reference
+// expression:  out = (c0*e0 + c1*e1 + c2*e2 + c3*e3) / denom   (terms with a NULL pointer are skipped)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lincomb4_kernel(const float *__restrict__ e0, const float *__restrict__ e1,
+                                                       const float *__restrict__ e2, const float *__restrict__ e3, float c0, float c1,
+                                                       float c2, float c3, float denom, long long n, float *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float a = c0 * e0[i];
+        if (e1) a = a + c1 * e1[i];
+        if (e2) a = a + c2 * e2[i];
+        if (e3) a = a + c3 * e3[i];
+        out[i] = a / denom;
+    }
+}
+
+extern "C" int gg_lincomb4(const float *e0, const float *e1, const float *e2, const float *e3, float c0, float c1, float c2, float c3,
+                           float denom, int64_t n, float *out, void *stream_)
+{
+    if (!e0 || !out) GG_FAIL(GG_ERR_BAD_SHAPE, "lincomb4: null pointer");
+    if (n <= 0) return GG_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, e0, e1, e2, e3, c0, c1, c2, c3, denom,
+                       (long long)n, out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // min-max normalisation over a whole tensor (ordered-uint atomics; deterministic)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2ord(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }

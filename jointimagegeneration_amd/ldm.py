@@ -535,3 +535,46 @@ class DDIMSampler(object):
                 elif eta != 0.0:
                     noise = torch.randn_like(st["x"])
                 step(noise)
+
+
+class PLMSSampler(DDIMSampler):
+    """Pseudo linear multistep sampler with the reference's surface (ldm/models/diffusion/plms.py:11-236): same schedule tables as
+    DDIM (eta must be 0), first step = pseudo improved Euler (two UNet evaluations), then Adams-Bashforth of order 2..4 over
+    the cached noise estimates; the update itself is the DDIM formula applied to the combined estimate e_t'."""
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        if ddim_eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")
+        super().make_schedule(ddim_num_steps, ddim_discretize, 0.0, verbose)
+
+    def run_steps(self, st, ctx_cl, eta, noise_tape):
+        unet = self.model.model.diffusion_model
+        Cx, Cc, S = st["Cx"], st["Cc"], st["S"]
+        xin = CL(st["unet_in"], Cx + Cc)
+        M = st["x"].numel() // Cx
+        x, eps, uin = st["x"].view(M, Cx), st["eps"], st["unet_in"].view(M, -1)
+        old: List[torch.Tensor] = []
+        e_prime = torch.empty_like(eps)
+
+        def update(e_cl, scal):
+            ops.ddim_step(x, e_cl.view(M, -1), scal, pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=uin)
+
+        for i in range(S):
+            unet.forward_cl(xin, st["table"][i], ctx_cl, head_out=eps)
+            e_t = eps.clone()
+            if len(old) == 0:
+                x_keep, uin_keep = x.clone(), uin.clone()
+                update(e_t, st["scal"][i])                                             # provisional x_prev
+                unet.forward_cl(xin, st["table"][min(i + 1, S - 1)], ctx_cl, head_out=eps)   # e(x_prev, t_next)
+                ops.lincomb4([e_t, eps], [1.0, 1.0], 2.0, e_prime)
+                x.copy_(x_keep); uin.copy_(uin_keep)
+            elif len(old) == 1:
+                ops.lincomb4([e_t, old[-1]], [3.0, -1.0], 2.0, e_prime)
+            elif len(old) == 2:
+                ops.lincomb4([e_t, old[-1], old[-2]], [23.0, -16.0, 5.0], 12.0, e_prime)
+            else:
+                ops.lincomb4([e_t, old[-1], old[-2], old[-3]], [55.0, -59.0, 37.0, -9.0], 24.0, e_prime)
+            update(e_prime, st["scal"][i])
+            old.append(e_t)
+            if len(old) >= 4:
+                old.pop(0)

@@ -335,3 +335,13 @@ def mask_to_cond_slice(labels: torch.Tensor, slice_idx: int, D: int, H: int, W: 
     N, Dm, Hm, Wm = labels.shape
     check(lib.gg_mask_to_cond_slice(labels.data_ptr(), N, Dm, Hm, Wm, slice_idx, D, H, W, _ptr(prev), cond.data_ptr(), cond.shape[-1],
                                     _ptr(mask_out), _stream()), "gg_mask_to_cond_slice")
+
+
+def lincomb4(es, coefs, denom: float, out: torch.Tensor) -> torch.Tensor:
+    """out = (sum_i coefs[i] * es[i]) / denom, fp32, left-to-right (PLMS multistep combination)."""
+    lib = _lib.load()
+    es = list(es) + [None] * (4 - len(es))
+    cs = list(coefs) + [0.0] * (4 - len(coefs))
+    check(lib.gg_lincomb4(es[0].data_ptr(), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]), cs[0], cs[1], cs[2], cs[3], denom, out.numel(),
+                          out.data_ptr(), _stream()), "gg_lincomb4")
+    return out

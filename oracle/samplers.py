@@ -192,6 +192,39 @@ def ddim_sample(eps_model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
     return img, pred_x0
 
 
+def plms_sample(eps_model, x_T, alphas_cumprod_f32, S: int, T: int = 1000):
+    """PLMSSampler.plms_sampling / p_sample_plms (ldm/models/diffusion/plms.py:118-236), eta = 0."""
+    sch = ddim_schedule(alphas_cumprod_f32, S, 0.0, T)
+    ts = sch["timesteps"]
+    total = ts.shape[0]
+    time_range = np.flip(ts)
+    img, old_eps, pred_x0 = x_T, [], None
+    zero = torch.zeros_like(x_T)
+
+    def upd(x, e, index):
+        return ddim_step(x, e, sch["alphas"][index], sch["alphas_prev"][index], sch["sigmas"][index],
+                         sch["sqrt_one_minus_alphas"][index], zero)
+    for i, step in enumerate(time_range):
+        index = total - i - 1
+        t = torch.full((img.shape[0],), int(step), dtype=torch.long)
+        t_next = torch.full((img.shape[0],), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        e_t = eps_model(img, t)
+        if len(old_eps) == 0:
+            x_prev, _ = upd(img, e_t, index)
+            e_t_prime = (e_t + eps_model(x_prev, t_next)) / 2
+        elif len(old_eps) == 1:
+            e_t_prime = (3 * e_t - old_eps[-1]) / 2
+        elif len(old_eps) == 2:
+            e_t_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+        else:
+            e_t_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+        img, pred_x0 = upd(img, e_t_prime, index)
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+    return img, pred_x0
+
+
 def slice_minmax_normalise(ds: torch.Tensor) -> torch.Tensor:
     """(ds - ds.min())/(ds.max()-ds.min()) over the WHOLE batch tensor (latentdiffusion/sample_diffusion.py:222)."""
     return (ds - ds.min()) / (ds.max() - ds.min())

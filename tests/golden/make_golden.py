@@ -405,6 +405,16 @@ def fx_chains(dd, oh, un, ldm):
     close(my_z, z, 1e-4, "DDIM 5-step latent")
     my_dec = O.ae_decode(sd_fs, my_z)
     close(my_dec, dec, 2e-4, "decode_first_stage")
+    # ---- PLMS, 10 steps (exercises the Euler start and Adams-Bashforth orders 2..4), same model / conditioning
+    pl = importlib.import_module("ldm.models.diffusion.plms")
+    pl.PLMSSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    ps = pl.PLMSSampler(m)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        with mock.patch.object(ut.torch, "randn", lambda *a, **k: torch.zeros(2, 4, 8, 8)):
+            zp, _ = ps.sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T)
+    my_zp, _ = S.plms_sample(eps, x_T, m.alphas_cumprod, 10)
+    close(my_zp, zp, 2e-4, "PLMS 10-step latent")
+    out.update(ldm_plms_z=zp)
     out.update(ldm_concat_cond=concat_cond, ldm_x_T=x_T, ldm_noises=torch.stack(noises), ldm_c=c, ldm_z=z, ldm_dec=dec)
     out["ldm_pipe_surface"] = surface(m)
     save("chains_small", **out)

@@ -460,6 +460,12 @@ def test_ldm_pipeline_ddim_chain(dev):
     assert rel_err(z, T(g["ldm_z"])) < 8e-2 and rms_err(z, T(g["ldm_z"])) < 3e-2
     dec = m.decode_first_stage(z)
     assert rel_err(dec, T(g["ldm_dec"])) < 1e-1 and rms_err(dec, T(g["ldm_dec"])) < 4e-2
+    # PLMS sampler on the same engine (plms.py:118-236): Euler start + Adams-Bashforth 2..4
+    from jointimagegeneration_amd.ldm import PLMSSampler
+    zp, _ = PLMSSampler(m).sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev))
+    assert rel_err(zp, T(g["ldm_plms_z"])) < 1e-1 and rms_err(zp, T(g["ldm_plms_z"])) < 4e-2
+    with pytest.raises(ValueError, match="must be 0 for PLMS"):
+        PLMSSampler(m).sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, eta=0.5)
     # hipGraph path == eager path, bit for bit (eta = 0, no tape)
     s2 = DDIMSampler(m)
     za, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)

@@ -226,3 +226,6 @@ def test_small_chains():
     assert torch.allclose(z, T(g["ldm_z"]), atol=2e-4 * float(np.abs(g["ldm_z"]).max()))
     dec = O.ae_decode(O.sub_state_dict(sd_all, "first_stage_model."), z)
     assert torch.allclose(dec, T(g["ldm_dec"]), atol=3e-4 * float(np.abs(g["ldm_dec"]).max()))
+    # PLMS (plms.py): 10 steps = Euler start + Adams-Bashforth orders 2, 3, 4
+    zp, _ = S.plms_sample(eps, T(g["ldm_x_T"]), m.alphas_cumprod, 10)
+    assert torch.allclose(zp, T(g["ldm_plms_z"]), atol=3e-4 * float(np.abs(g["ldm_plms_z"]).max()))
