@@ -381,6 +381,9 @@ extern "C" int gg_conv_pack_weight(const float *w, int32_t Cout, int32_t Cin, in
 
 // halo fast path (gg_conv_halo.hip); returns GG_ERR_UNSUPPORTED when the shape is outside its envelope
 int gg_conv_halo_try(const ConvParams &p, hipStream_t stream);
+// tiny-M weight-streaming path (gg_conv_tiny.hip): plan returns 0 (not applicable) or the K split
+int gg_conv_tiny_plan(long long M, int Cout_pad, int KS, int prologue_act);
+int gg_conv_tiny_launch(const ConvParams &p, hipStream_t stream);
 
 template <int NT>
 static int launch_gather(const ConvParams &p, hipStream_t stream)
@@ -431,6 +434,7 @@ extern "C" int64_t gg_conv_workspace_bytes(const gg_conv_desc *d)
     if (!d) return 0;
     long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     int KS = d->kd * d->kh * d->kw * ((d->C1 + d->C2) / 32);
+    if (int tsk = gg_conv_tiny_plan(M, d->Cout_pad, KS, d->prologue_act)) return tsk > 1 ? (int64_t)tsk * M * d->Cout_pad * 4 : 0;
     GatherPlan pl = plan_gather(M, d->Cout_pad, KS);
     return pl.splitk > 1 ? (int64_t)pl.splitk * M * d->Cout_pad * 4 : 0;
 }
@@ -492,6 +496,23 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
 
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;
+
+    if (int tsk = gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, p.prologue_act)) {
+        if (tsk > 1) {
+            const long long need = (long long)tsk * p.M * p.Cout_pad * 4;
+            if (!d->workspace || d->workspace_bytes < need)
+                GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "conv: split-K needs %lld workspace bytes (gg_conv_workspace_bytes), got %lld", need, (long long)d->workspace_bytes);
+            p.ws = (float *)d->workspace;
+        }
+        p.splitk = tsk;
+        rc = gg_conv_tiny_launch(p, stream);
+        if (rc != GG_OK || tsk == 1) return rc;
+        long long total = p.M * (p.Cout_pad / 4);
+        long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        GG_CHECK_LAUNCH();
+        return GG_OK;
+    }
 
     GatherPlan pl = plan_gather(p.M, p.Cout_pad, p.ntaps * p.nchunk);
     if (pl.splitk > 1) {
