@@ -299,6 +299,187 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------ 160-channel-step gather
+// Variant for channel counts that are multiples of 160 (the LDM UNet: 160/320/480/.../1600): one k-step covers FIVE
+// 32-channel chunks of one tap.  A thread gathers 5 x 16 B of ONE position row per step (one bounds check / address), the
+// weight tile of a step is 10 KiB contiguous in the packed layout, and the per-k-step overhead (barrier, loop, waits,
+// address math: ~110 instructions in the 32-channel kernel) is paid once per 160 channels.  Tile 64 positions x 32 couts.
+template <int PRO>
+__global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
+{
+    constexpr int BM = 64, CPS = 5;
+    constexpr int XT = BM * 64, WT = 32 * 64;                       // one 32-channel tile of X / W in LDS
+    constexpr int STAGE = CPS * (XT + WT);                           // 30 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int g0 = blockIdx.y;
+
+    // gather duty: row tid>>2, 16-byte slot tid&3 of each of the 5 chunks
+    const int xrow = tid >> 2, xq = tid & 3;
+    const unsigned osp = (unsigned)(p.Do * p.Ho * p.Wo), ohw = (unsigned)(p.Ho * p.Wo);
+    bool rv;
+    int bn, bd, bh, bw;
+    const bf16_t *rb1, *rb2;
+    {
+        long long m = m0 + xrow;
+        rv = m < p.M;
+        unsigned mu = rv ? (unsigned)m : 0u;
+        unsigned n = mu / osp, r = mu - n * osp;
+        unsigned od = r / ohw;
+        r -= od * ohw;
+        unsigned oh = r / (unsigned)p.Wo, ow = r - oh * (unsigned)p.Wo;
+        bn = (int)n;
+        bd = (p.kd == 1) ? (int)od * p.stride : (int)od * p.stride - p.pad;
+        bh = (p.kh == 1) ? (int)oh * p.stride : (int)oh * p.stride - p.pad;
+        bw = (p.kw == 1) ? (int)ow * p.stride : (int)ow * p.stride - p.pad;
+        const long long sp = (long long)p.D * p.H * p.W;
+        rb1 = p.src1 + (long long)n * sp * p.C1 + xq * 8;
+        rb2 = p.src2 ? p.src2 + (long long)n * sp * p.C2 + xq * 8 : nullptr;
+    }
+    const int upD = (p.upsample && p.kd == 3) ? 1 : 0, upHW = p.upsample ? 1 : 0;
+    const unsigned limD = (unsigned)(p.D << upD), limH = (unsigned)(p.H << upHW), limW = (unsigned)(p.W << upHW);
+    const int gnC = p.C1 + p.C2;
+
+    // k-steps: (group of 5 chunks) outer, tap inner
+    const int ngrp = p.nchunk / CPS, ngrp1 = p.nchunk1 / CPS;
+    const int KS_all = ngrp * p.ntaps;
+    const int ks_begin = (int)(((long long)KS_all * blockIdx.z) / p.splitk);
+    const int ks_end = (int)(((long long)KS_all * (blockIdx.z + 1)) / p.splitk);
+    int grp = ks_begin / p.ntaps, tap = ks_begin - grp * p.ntaps;
+    int tkd = tap / (p.kh * p.kw), tkh = (tap / p.kw) % p.kh, tkw = tap % p.kw;
+
+    u32x4 xreg[2][CPS], wreg[2][3];
+    int xso[2];
+    auto load_regs = [&](u32x4 (&xr)[CPS], u32x4 (&wr)[3], int &so) {
+        const bool second = grp >= ngrp1;
+        const int Cs = second ? p.C2 : p.C1;
+        const int coff = (second ? grp - ngrp1 : grp) * (CPS * 32);
+        const unsigned ud = (unsigned)(bd + tkd), uh = (unsigned)(bh + tkh), uw = (unsigned)(bw + tkw);
+        const bool ok = rv && ud < limD && uh < limH && uw < limW;
+        so = -1;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) xr[c] = u32x4{0u, 0u, 0u, 0u};
+        if (ok) {
+            const unsigned pos = ((ud >> upD) * (unsigned)p.H + (uh >> upHW)) * (unsigned)p.W + (uw >> upHW);
+            const bf16_t *src = (second ? rb2 : rb1) + (pos * (unsigned)Cs + (unsigned)coff);
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) xr[c] = *reinterpret_cast<const u32x4 *>(src + c * 32);
+            so = bn * gnC + grp * (CPS * 32) + xq * 8;
+        }
+        // 5 consecutive packed tiles (chunks 5*grp..5*grp+4 of this tap): 10 KiB contiguous
+        const bf16_t *wsrc = p.weight + ((((long long)g0 * p.ntaps + tap) * p.nchunk + grp * CPS) << 10);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + 256 * j;
+            if (i < CPS * 128) wr[j] = *reinterpret_cast<const u32x4 *>(wsrc + i * 8);
+        }
+        if (++tkw == p.kw) {
+            tkw = 0;
+            if (++tkh == p.kh) {
+                tkh = 0;
+                if (++tkd == p.kd) { tkd = 0; tap = -1; ++grp; }
+            }
+        }
+        ++tap;
+    };
+    auto write_lds = [&](int buf, u32x4 (&xr)[CPS], u32x4 (&wr)[3], int so) {
+        char *xb = smem + buf * STAGE;
+        char *wb = xb + CPS * XT;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+            u32x4 v = xr[c];
+            if (PRO && so >= 0) {
+                const float *sc = p.gn_scale + so + c * 32, *sh = p.gn_shift + so + c * 32;
+                f32x4 s0 = *reinterpret_cast<const f32x4 *>(sc), s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+                f32x4 h0 = *reinterpret_cast<const f32x4 *>(sh), h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+                bf16x8 xb8 = __builtin_bit_cast(bf16x8, v), yb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y0 = (float)xb8[j] * s0[j] + h0[j], y1 = (float)xb8[j + 4] * s1[j] + h1[j];
+                    if (p.prologue_act == 1) {
+                        y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                        y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                    }
+                    yb[j] = (bf16_t)y0;
+                    yb[j + 4] = (bf16_t)y1;
+                }
+                v = __builtin_bit_cast(u32x4, yb);
+            }
+            *reinterpret_cast<u32x4 *>(xb + c * XT + xrow * 64 + swz64(xrow, xq) * 16) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + 256 * j;
+            if (i < CPS * 128) *reinterpret_cast<u32x4 *>(wb + i * 16) = wr[j];     // 5 pre-swizzled 2 KiB tiles, linear
+        }
+    };
+
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto compute = [&](int buf) {
+        const char *xb = smem + buf * STAGE;
+        const char *wb = xb + CPS * XT;
+        const int r = wave * 16 + fr;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8 *>(xb + c * XT + r * 64 + swz64(r, fq) * 16);
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(wb + c * WT + fr * 64 + swz64(fr, fq) * 16);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(wb + c * WT + (16 + fr) * 64 + swz64(16 + fr, fq) * 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xf, acc[1], 0, 0, 0);
+        }
+    };
+
+    const int KS = ks_end - ks_begin;
+    if (KS > 0) load_regs(xreg[0], wreg[0], xso[0]);
+    if (KS > 1) load_regs(xreg[1], wreg[1], xso[1]);
+    for (int ks0 = 0; ks0 < KS; ks0 += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ks = ks0 + j;
+            if (ks < KS) {
+                const int buf = ks & 1;
+                write_lds(buf, xreg[j], wreg[j], xso[j]);
+                __syncthreads();
+                if (ks + 2 < KS) load_regs(xreg[j], wreg[j], xso[j]);
+                compute(buf);
+            }
+        }
+    }
+
+    const long long m = m0 + wave * 16 + fr;
+    if (m >= p.M) return;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int co = g0 * 32 + ct * 16 + fq * 4;
+        f32x4 v = acc[ct];
+        const long long o = m * p.Cout_pad + co;
+        if (p.splitk > 1) {
+            *reinterpret_cast<f32x4 *>(p.ws + (long long)blockIdx.z * p.M * p.Cout_pad + o) = v;
+            continue;
+        }
+        if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + (long long)((unsigned)m / osp) * p.bias_stride + co);
+        if (p.residual) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (co + j >= p.Cout) v[j] = 0.f;
+        if (p.out_dtype == GG_F32) {
+            *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+        } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ split-K reduce
 // out[m, co] = sum_z slab[z][m][co] (fixed order: deterministic) + bias[n][co] (+ residual) -> bf16 / fp32
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p)
@@ -429,12 +610,31 @@ static GatherPlan plan_gather(long long M, int Cout_pad, int KS)
     return {NT, splitk};
 }
 
+// 160-channel-step variant: 0 = not applicable, else the K split
+static int plan_gather5(long long M, int C1, int C2, int Cout_pad, int ntaps)
+{
+    static const int enabled = [] { const char *e = getenv("GG_GATHER5"); return e ? atoi(e) : 1; }();
+    if (!enabled || C1 % 160 || C2 % 160) return 0;
+    const long long blocks = ((M + 63) / 64) * (Cout_pad / 32);
+    if (blocks >= 4096) return 0;                                   // big grids: the wide-tile kernel has more MFMA per LDS byte
+    const int KS5 = ((C1 + C2) / 160) * ntaps;
+    static const int g5_target = [] { const char *e = getenv("GG_G5_TARGET"); return e ? atoi(e) : 320; }();
+    static const int g5_minsteps = [] { const char *e = getenv("GG_G5_MINSTEPS"); return e ? atoi(e) : 5; }();
+    long long sk = (g5_target + blocks - 1) / blocks;
+    long long maxs = KS5 / g5_minsteps > 0 ? KS5 / g5_minsteps : 1;
+    if (sk > maxs) sk = maxs;
+    if (sk < 1) sk = 1;
+    if (sk > 32) sk = 32;
+    return (int)sk;
+}
+
 extern "C" int64_t gg_conv_workspace_bytes(const gg_conv_desc *d)
 {
     if (!d) return 0;
     long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     int KS = d->kd * d->kh * d->kw * ((d->C1 + d->C2) / 32);
     if (int tsk = gg_conv_tiny_plan(M, d->Cout_pad, KS, d->prologue_act)) return tsk > 1 ? (int64_t)tsk * M * d->Cout_pad * 4 : 0;
+    if (int s5 = plan_gather5(M, d->C1, d->C2, d->Cout_pad, d->kd * d->kh * d->kw)) return s5 > 1 ? (int64_t)s5 * M * d->Cout_pad * 4 : 0;
     GatherPlan pl = plan_gather(M, d->Cout_pad, KS);
     return pl.splitk > 1 ? (int64_t)pl.splitk * M * d->Cout_pad * 4 : 0;
 }
@@ -511,6 +711,28 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
         long long blocks = (total + 255) / 256;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
         GG_CHECK_LAUNCH();
+        return GG_OK;
+    }
+
+    if (int s5 = plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps)) {
+        if (s5 > 1) {
+            const long long need = (long long)s5 * p.M * p.Cout_pad * 4;
+            if (!d->workspace || d->workspace_bytes < need)
+                GG_FAIL(GG_ERR_WORKSPACE_TOO_SMALL, "conv: split-K needs %lld workspace bytes (gg_conv_workspace_bytes), got %lld", need, (long long)d->workspace_bytes);
+            p.ws = (float *)d->workspace;
+        }
+        p.splitk = s5;
+        dim3 grid((unsigned)((p.M + 63) / 64), (unsigned)(p.Cout_pad / 32), (unsigned)s5);
+        if (p.prologue_act) hipLaunchKernelGGL(conv_gather5_kernel<1>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_gather5_kernel<0>, grid, dim3(256), 0, stream, p);
+        GG_CHECK_LAUNCH();
+        if (s5 > 1) {
+            long long total = p.M * (p.Cout_pad / 4);
+            long long blocks = (total + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+            GG_CHECK_LAUNCH();
+        }
         return GG_OK;
     }
 

@@ -183,6 +183,36 @@ def test_splitk_in_launch_combine_is_bit_identical_and_self_cleaning(dev):
     ops.IN_LAUNCH_SPLITK_COMBINE = False
 
 
+def test_conv_gather5_two_source_prologue_residual(dev):
+    """160-channel-step gather variant (channel counts that are multiples of 160): fused concat, GN prologue, residual, split-K."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(8)
+    N, C1, C2, Cout, sp = 1, 320, 160, 160, (24, 20)
+    x1, x2 = torch.randn((N, C1) + sp, generator=g), torch.randn((N, C2) + sp, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn((N, Cout) + sp, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C1 + C2, generator=g), 0.1 * torch.randn(C1 + C2, generator=g)
+    xc = torch.cat([bf(x1), bf(x2)], 1)
+    c1, c2 = ops.to_cl(x1.to(dev)), ops.to_cl(x2.to(dev))
+    scale, shift = ops.groupnorm_stats(c1, gamma.to(dev), beta.to(dev), 1e-5, src2=c2)
+    pw, pb = ops.pack_conv_weight(w.to(dev), C1 + C2), ops.pad_bias(b.to(dev), Cout, dev)
+    ref0 = O.conv(xc, bf(w), b, padding=1) + bf(res)
+    out0 = ops.conv(c1, pw, pb, Cout, k=(1, 3, 3), src2=c2, residual=ops.to_cl(res.to(dev)))
+    assert rel_err(ops.from_cl(out0, 2), ref0) < 1e-2
+    ref1 = O.conv(bf(O.silu(O.group_norm(xc, gamma, beta, 1e-5))), bf(w), b, padding=1) + bf(res)
+    out1 = ops.conv(c1, pw, pb, Cout, k=(1, 3, 3), src2=c2, residual=ops.to_cl(res.to(dev)), prologue=(scale, shift))
+    assert rel_err(ops.from_cl(out1, 2), ref1) < 1.5e-2
+    # stride 2 and 1x1 through the same variant
+    w1 = torch.randn(320, 160, 1, 1, generator=g) / math.sqrt(160)
+    xs = torch.randn(2, 160, 16, 16, generator=g)
+    o = ops.conv(ops.to_cl(xs.to(dev)), ops.pack_conv_weight(w1.to(dev), 160), None, 320, k=(1, 1, 1), pad=0)
+    assert rel_err(ops.from_cl(o, 2), O.conv(bf(xs), bf(w1))) < 1e-2
+    w2 = torch.randn(160, 160, 3, 3, generator=g) / math.sqrt(160 * 9)
+    o = ops.conv(ops.to_cl(xs.to(dev)), ops.pack_conv_weight(w2.to(dev), 160), None, 160, k=(1, 3, 3), stride=2, pad=1)
+    assert rel_err(ops.from_cl(o, 2), O.conv(bf(xs), bf(w2), stride=2, padding=1)) < 1e-2
+
+
 def test_conv_rejects_bad_shapes(dev):
     from jointimagegeneration_amd import ops
     x = ops.to_cl(torch.randn(1, 32, 4, 4, device=dev))
