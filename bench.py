@@ -134,6 +134,8 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    if os.environ.get("GG_SINGLE_DEVICE") == "1":      # rehearsal of N > 1 ranks on a one-GPU box (all ranks share cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from jointimagegeneration_amd import distributed as ggd

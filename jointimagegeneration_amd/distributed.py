@@ -22,7 +22,7 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
     """backend 'nccl' (= RCCL on ROCm) for GPU ranks, 'gloo' for CPU rehearsals; MASTER_ADDR/PORT come from the launcher."""
     rank, _, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = os.environ.get("GG_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return rank, world
@@ -48,7 +48,8 @@ def timed_region(fn: Callable[[], None], device: Optional[torch.device] = None) 
     barrier(device)
     elapsed = time.time() - t0
     if dist.is_available() and dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if (device is not None and device.type == "cuda") else "cpu")
+        on_gpu = device is not None and device.type == "cuda" and dist.get_backend() == "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
