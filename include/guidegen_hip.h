@@ -183,6 +183,12 @@ int gg_labels_to_onehot(const int32_t *labels, int64_t M, int32_t K, void *oneho
 int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev,
                  int64_t M, int32_t C, float *pred_x0_out, void *unet_in, int32_t unet_in_stride, void *stream);
 
+/* Ancestral DDPM step (LatentDiffusion.p_sample: ldm/models/diffusion/ddpm.py:217-230,1060-1120), fp32 elementwise:
+ *   x_recon = s[0]*x - s[1]*eps ; mean = s[2]*x_recon + s[3]*x ; x <- mean + s[4]*noise   (scalars device fp32[5],
+ *   s[4] = (t > 0) * exp(0.5 * posterior_log_variance_clipped[t]); noise may be NULL). unet_in as in gg_ddim_step. */
+int gg_ddpm_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev, int64_t M, int32_t C,
+                 void *unet_in, int32_t unet_in_stride, void *stream);
+
 /* PLMS multistep combination of noise estimates (ldm/models/diffusion/plms.py:218-232), fp32, evaluated left to right:
  *   out = (c0*e0 + c1*e1 + c2*e2 + c3*e3) / denom ; e1..e3 may be NULL (skipped). */
 int gg_lincomb4(const float *e0, const float *e1, const float *e2, const float *e3, float c0, float c1, float c2, float c3,

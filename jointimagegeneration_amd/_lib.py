@@ -60,6 +60,7 @@ SIGNATURES = {
     "gg_labels_to_onehot": (C.c_int, [vp, i64, i32, vp, i32, vp]),
     "gg_ddim_step": (C.c_int, [vp, vp, i32, vp, vp, i64, i32, vp, vp, i32, vp]),
     "gg_minmax_normalise": (C.c_int, [vp, i64, vp, vp, vp]),
+    "gg_ddpm_step": (C.c_int, [vp, vp, i32, vp, vp, i64, i32, vp, i32, vp]),
     "gg_lincomb4": (C.c_int, [vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp, vp]),
     "gg_mask_to_cond_slice": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
 }

@@ -220,6 +220,46 @@ extern "C" int gg_ddim_step(float *x, const float *eps, int32_t eps_stride, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Ancestral DDPM step (LatentDiffusion.p_sample, ldm/models/diffusion/ddpm.py:217-230,1060-1120), fp32, same order:
+//   x_recon = sqrt_recip_ac*x - sqrt_recipm1_ac*eps ; mean = coef1*x_recon + coef2*x ; x_prev = mean + sigma*noise
+//   scalars device fp32[5] = {sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t], posterior_mean_coef1[t],
+//                             posterior_mean_coef2[t], (t > 0) * exp(0.5*posterior_log_variance_clipped[t])}
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddpm_step_kernel(float *__restrict__ x, const float *__restrict__ eps, int eps_stride,
+                                                        const float *__restrict__ noise, const float *__restrict__ sc, long long M,
+                                                        int C, bf16_t *__restrict__ unet_in, int unet_in_stride)
+{
+#pragma clang fp contract(off)
+    const float a = sc[0], b = sc[1], c1 = sc[2], c2 = sc[3], sg = sc[4];
+    const long long total = M * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        const float xv = x[i];
+        const float xr = a * xv - b * eps[m * eps_stride + c];
+        float xn = c1 * xr + c2 * xv;
+        if (noise) xn = xn + sg * noise[i];
+        x[i] = xn;
+        if (unet_in) unet_in[m * unet_in_stride + c] = (bf16_t)xn;
+    }
+}
+
+extern "C" int gg_ddpm_step(float *x, const float *eps, int32_t eps_stride, const float *noise, const float *scalars_dev, int64_t M,
+                            int32_t C, void *unet_in, int32_t unet_in_stride, void *stream_)
+{
+    if (!x || !eps || !scalars_dev) GG_FAIL(GG_ERR_BAD_SHAPE, "ddpm_step: null pointer");
+    if (eps_stride < C || (unet_in && unet_in_stride < C)) GG_FAIL(GG_ERR_BAD_SHAPE, "ddpm_step: stride < C");
+    long long total = (long long)M * C;
+    if (total <= 0) return GG_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, eps, eps_stride, noise, scalars_dev,
+                       (long long)M, C, (bf16_t *)unet_in, unet_in_stride);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // PLMS noise-estimate combination (ldm/models/diffusion/plms.py:218-232), fp32, same left-to-right order as the reference
 // expression:  out = (c0*e0 + c1*e1 + c2*e2 + c3*e3) / denom   (terms with a NULL pointer are skipped)
 // ------------------------------------------------------------------------------------------------------------

@@ -374,6 +374,54 @@ class LatentDiffusion(nn.Module):
             cond = {key: cond}
         return self.model(x_noisy, t, **cond)
 
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None, log_every_t=None,
+                      noise_tape=None):
+        """Vanilla ancestral sampling over all `num_timesteps` (ddpm.py:1179-1227 + p_sample :1092-1120), channels-last on the
+        GPU: per step one UNet forward + one fused `gg_ddpm_step`.  clip_denoised is False for LatentDiffusion (ddpm.py:477)."""
+        if mask is not None or quantize_denoised:
+            raise NotImplementedError("inpainting / quantised denoising are not on the scoped path")
+        dev = self.device
+        unet = self.model.diffusion_model
+        ck = self.model.conditioning_key
+        N, Cx = shape[0], shape[1]
+        sp = tuple(shape[2:])
+        sp3 = (1,) * (3 - len(sp)) + sp
+        nd = len(sp)
+        T = self.num_timesteps if timesteps is None else timesteps
+        if start_T is not None:
+            T = min(T, start_T)
+        c_concat = cond if (cond is not None and ck == "concat" and not isinstance(cond, dict)) else \
+            (cond.get("c_concat", [None])[0] if isinstance(cond, dict) else None)
+        context = cond if (cond is not None and ck == "crossattn" and not isinstance(cond, dict)) else None
+        Cc = c_concat.shape[1] if c_concat is not None else 0
+        perm = (0,) + tuple(range(2, nd + 2)) + (1,)
+        img = torch.randn(tuple(shape), device=dev) if x_T is None else x_T.to(dev).float()
+        x = img.permute(perm).contiguous().view((N,) + sp3 + (Cx,))
+        unet_in = torch.zeros((N,) + sp3 + (pad32(Cx + Cc),), dtype=torch.bfloat16, device=dev)
+        ops.to_cl(img, out=unet_in, c_offset=0, zero_fill=False)
+        if c_concat is not None:
+            ops.to_cl(c_concat.float(), out=unet_in, c_offset=Cx, zero_fill=False)
+        ctx_cl = unet.context_cl(context) if context is not None else None
+        ts = torch.arange(T - 1, -1, -1, device=dev)
+        table = unet.time_bias_table(ts.float(), N)
+        sig = torch.exp(0.5 * self.posterior_log_variance_clipped[ts]) * (ts > 0).float()
+        scal = torch.stack([self.sqrt_recip_alphas_cumprod[ts], self.sqrt_recipm1_alphas_cumprod[ts], self.posterior_mean_coef1[ts],
+                            self.posterior_mean_coef2[ts], sig], 1).float().contiguous()
+        eps = torch.empty((N,) + sp3 + (pad32(unet.out_channels),), dtype=torch.float32, device=dev)
+        M = x.numel() // Cx
+        xin = CL(unet_in, Cx + Cc)
+        for i in range(T):
+            unet.forward_cl(xin, table[i], ctx_cl, head_out=eps)
+            if noise_tape is not None:
+                nz = noise_tape[i].to(dev).float().permute(perm).contiguous()
+            else:
+                nz = torch.randn_like(x)
+            ops.ddpm_step(x.view(M, Cx), eps.view(M, -1), scal[i], noise=nz.view(M, Cx), unet_in=unet_in.view(M, -1))
+        out = x.view((N,) + sp + (Cx,)).permute((0, nd + 1) + tuple(range(1, nd + 1))).contiguous()
+        return (out, [img, out]) if return_intermediates else out
+
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise
         sh = (-1,) + (1,) * (x_start.ndim - 1)

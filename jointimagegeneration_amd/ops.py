@@ -345,3 +345,13 @@ def lincomb4(es, coefs, denom: float, out: torch.Tensor) -> torch.Tensor:
     check(lib.gg_lincomb4(es[0].data_ptr(), _ptr(es[1]), _ptr(es[2]), _ptr(es[3]), cs[0], cs[1], cs[2], cs[3], denom, out.numel(),
                           out.data_ptr(), _stream()), "gg_lincomb4")
     return out
+
+
+def ddpm_step(x: torch.Tensor, eps: torch.Tensor, scalars: torch.Tensor, noise: Optional[torch.Tensor] = None,
+              unet_in: Optional[torch.Tensor] = None) -> None:
+    """Ancestral DDPM update in place; x fp32 CL [M, C], eps fp32 CL [M, stride], scalars fp32[5] on device."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    check(lib.gg_ddpm_step(x.data_ptr(), eps.data_ptr(), eps.shape[-1], _ptr(noise), scalars.data_ptr(), M, Cc, _ptr(unet_in),
+                           unet_in.shape[-1] if unet_in is not None else 0, _stream()), "gg_ddpm_step")

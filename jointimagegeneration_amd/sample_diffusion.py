@@ -22,7 +22,7 @@ import torch
 
 from .config import apply_dotlist, instantiate_from_config, load_yaml, merge
 from .io import load_checkpoint, write_nifti
-from .ldm import DDIMSampler
+from .ldm import DDIMSampler, PLMSSampler
 from .synth import randomize_parameters, synth_mask_volume
 
 
@@ -31,7 +31,8 @@ def get_parser():
     p.add_argument("-r", "--resume", type=str, nargs="?", help="load from logdir or checkpoint in logdir")
     p.add_argument("-n", "--n_samples", type=int, nargs="?", default=1, help="number of samples to draw")
     p.add_argument("-e", "--eta", type=float, nargs="?", default=0.0, help="eta for ddim sampling (0.0 yields deterministic sampling)")
-    p.add_argument("-v", "--vanilla_sample", default=False, action="store_true", help="vanilla sampling (not implemented: DDIM only)")
+    p.add_argument("-v", "--vanilla_sample", default=False, action="store_true", help="vanilla ancestral sampling (default: DDIM)")
+    p.add_argument("--plms", default=False, action="store_true", help="PLMS sampler instead of DDIM")
     p.add_argument("-l", "--logdir", type=str, nargs="?", default="none", help="extra logdir")
     p.add_argument("-c", "--custom_steps", type=int, nargs="?", default=50, help="number of steps for ddim sampling")
     p.add_argument("--batch_size", type=int, nargs="?", default=1)
@@ -74,10 +75,10 @@ def strip_ckpt_paths(cfg):
 
 
 @torch.no_grad()
-def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise_seed=None):
+def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise_seed=None, vanilla=False, plms=False):
     """The reference slice loop (sample_diffusion.py:196-224) on the reference-shaped API. instance["wholemask"] is
     [1, D, H, W, 1] (label/255); returns pred [n, 2, D, H, W] = cat([samples, gen_mask])."""
-    sampler = DDIMSampler(model)
+    sampler = PLMSSampler(model) if plms else DDIMSampler(model)
     with model.ema_scope():
         wholemask = instance["wholemask"].permute(0, 4, 1, 2, 3).cuda()
         nz = torch.where(wholemask.sum((0, 1, 3, 4)))[0]
@@ -91,8 +92,11 @@ def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise
             concat_cond = torch.cat([samples[:, :, max(0, m_ - 1)], gen_mask[:, :, m_]], axis=1)
             c = model.get_learned_conditioning(concat_cond)
             x_T = torch.randn((n_samples,) + shape, generator=g, device=wholemask.device) if g is not None else None
-            s, _ = sampler.sample(S=ddim_steps, dims=len(shape) - 1, conditioning=c, batch_size=n_samples, shape=shape, verbose=False,
-                                  eta=ddim_eta, x_T=x_T)
+            if vanilla:
+                s = model.p_sample_loop(c, (n_samples,) + shape, x_T=x_T, verbose=False)
+            else:
+                s, _ = sampler.sample(S=ddim_steps, dims=len(shape) - 1, conditioning=c, batch_size=n_samples, shape=shape,
+                                      verbose=False, eta=ddim_eta, x_T=x_T)
             ds = model.decode_first_stage(s)
             samples[:, :, m_] = (ds - ds.min()) / (ds.max() - ds.min())
         return torch.cat([samples, gen_mask], dim=1)
@@ -125,7 +129,8 @@ def main(argv=None):
         lab = synth_mask_volume(opt.slices, opt.size, opt.size)
     instance = {"wholemask": (lab.float() / 255.0)[None, ..., None]}
     t0 = time.time()
-    pred = sample_cond(model, instance, n_samples=opt.n_samples, ddim_steps=opt.custom_steps, ddim_eta=opt.eta, noise_seed=opt.seed)
+    pred = sample_cond(model, instance, n_samples=opt.n_samples, ddim_steps=opt.custom_steps, ddim_eta=opt.eta, noise_seed=opt.seed,
+                       vanilla=opt.vanilla_sample, plms=opt.plms)
     torch.cuda.synchronize()
     out_dir = os.path.join(logdir if logdir != "none" else ".", "samples", f"{global_step:08}")
     os.makedirs(out_dir, exist_ok=True)

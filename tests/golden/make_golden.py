@@ -415,6 +415,20 @@ def fx_chains(dd, oh, un, ldm):
     my_zp, _ = S.plms_sample(eps, x_T, m.alphas_cumprod, 10)
     close(my_zp, zp, 2e-4, "PLMS 10-step latent")
     out.update(ldm_plms_z=zp)
+    # ---- vanilla ancestral sampling (p_sample_loop), a 20-step schedule with the same networks and conditioning
+    with contextlib.redirect_stdout(io.StringIO()):
+        m20 = dm.LatentDiffusion(first_stage_config=cfg_ae, cond_stage_config=cfg_cond, unet_config=cfg_unet,
+                                 linear_start=0.0015, linear_end=0.0195, timesteps=20, image_size=8, channels=4, dims=2,
+                                 first_stage_key="image", cond_stage_key="mask", num_timesteps_cond=1).eval()
+    randomize_parameters(m20, SEED, "ldm_pipe.")
+    gen20 = g(4096)
+    nz20 = [torch.randn(2, 4, 8, 8, generator=gen20) for _ in range(20)]
+    tape20 = iter(nz20)
+    with mock.patch.object(ut.torch, "randn", lambda *a, **k: next(tape20)):
+        zv = m20.p_sample_loop(c, (2, 4, 8, 8), x_T=x_T, verbose=False)
+    my_zv = S.ddpm_ancestral_sample(eps, x_T, nz20, S.ldm_linear_betas(20, 0.0015, 0.0195))
+    close(my_zv, zv, 2e-4, "vanilla 20-step latent")
+    out.update(ldm_vanilla_z=zv, ldm_vanilla_noises=torch.stack(nz20))
     out.update(ldm_concat_cond=concat_cond, ldm_x_T=x_T, ldm_noises=torch.stack(noises), ldm_c=c, ldm_z=z, ldm_dec=dec)
     out["ldm_pipe_surface"] = surface(m)
     save("chains_small", **out)

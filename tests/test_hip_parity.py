@@ -496,6 +496,12 @@ def test_ldm_pipeline_ddim_chain(dev):
     assert rel_err(zp, T(g["ldm_plms_z"])) < 1e-1 and rms_err(zp, T(g["ldm_plms_z"])) < 4e-2
     with pytest.raises(ValueError, match="must be 0 for PLMS"):
         PLMSSampler(m).sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, eta=0.5)
+    # vanilla ancestral sampling (LatentDiffusion.p_sample_loop) on a 20-step schedule, same networks (same parameter names)
+    m20 = seeded(LatentDiffusion(first_stage_config=cfg_ae, cond_stage_config=cfg_cond, unet_config=cfg_unet, linear_start=0.0015,
+                                 linear_end=0.0195, timesteps=20, image_size=8, channels=4, dims=2, first_stage_key="image",
+                                 cond_stage_key="mask", num_timesteps_cond=1), "ldm_pipe.").to(dev)
+    zv = m20.p_sample_loop(c, (2, 4, 8, 8), x_T=T(g["ldm_x_T"]).to(dev), verbose=False, noise_tape=list(T(g["ldm_vanilla_noises"])))
+    assert rel_err(zv, T(g["ldm_vanilla_z"])) < 1e-1 and rms_err(zv, T(g["ldm_vanilla_z"])) < 4e-2
     # hipGraph path == eager path, bit for bit (eta = 0, no tape)
     s2 = DDIMSampler(m)
     za, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)

@@ -229,3 +229,6 @@ def test_small_chains():
     # PLMS (plms.py): 10 steps = Euler start + Adams-Bashforth orders 2, 3, 4
     zp, _ = S.plms_sample(eps, T(g["ldm_x_T"]), m.alphas_cumprod, 10)
     assert torch.allclose(zp, T(g["ldm_plms_z"]), atol=3e-4 * float(np.abs(g["ldm_plms_z"]).max()))
+    # vanilla ancestral sampling (p_sample_loop) on a 20-step schedule
+    zv = S.ddpm_ancestral_sample(eps, T(g["ldm_x_T"]), list(T(g["ldm_vanilla_noises"])), S.ldm_linear_betas(20, 0.0015, 0.0195))
+    assert torch.allclose(zv, T(g["ldm_vanilla_z"]), atol=3e-4 * float(np.abs(g["ldm_vanilla_z"]).max()))
