@@ -561,3 +561,56 @@ def test_entry_points_run_on_small_configs(dev, tmp_path):
     sample_diffusion.main(["-r", str(logdir), "-c", "5", "-n", "2", "--slices", "4", "--size", "32"])
     outs = sorted((logdir / "samples" / "00000000").glob("sample_*.nii.gz"))
     assert len(outs) == 2
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE full sizes
+def test_full_size_conv3d_properties(dev):
+    """128^3 x 64 -> 64 conv (the dominant launch of config C3/C5) is too large for the CPU oracle in a unit test, so it is
+    checked through size-independent properties that are EXACT in bf16: homogeneity under power-of-two scaling, shift
+    equivariance away from the border (exercises every halo/tile seam), repeatability, and agreement with the oracle on a
+    cropped sub-volume whose receptive field lies inside the crop."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    S = 128
+    x = torch.randn(1, S, S, S, 64, generator=g, device=dev).bfloat16()
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g, device=dev) / math.sqrt(64 * 27))
+    pw = ops.pack_conv_weight(w, 64)
+    assert ops.conv_fuses_prologue(ops.CL(x, 64), 64, k=(3, 3, 3))            # this shape runs on the halo-tile kernel
+    y = ops.conv(ops.CL(x, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
+    y2 = ops.conv(ops.CL(x, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
+    assert torch.equal(y, y2)                                                   # repeatable bit for bit
+    ys = ops.conv(ops.CL(x * 4, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
+    assert torch.equal(ys, y * 4)                                               # exact: x4 only changes exponents
+    sh = (5, 9, 17)                                                             # crosses tile seams in D, H and W
+    xr = torch.roll(x, shifts=sh, dims=(1, 2, 3))
+    yr = ops.conv(ops.CL(xr, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
+    a = yr[:, sh[0] + 1:S - 1, sh[1] + 1:S - 1, sh[2] + 1:S - 1]
+    b = y[:, 1:S - 1 - sh[0], 1:S - 1 - sh[1], 1:S - 1 - sh[2]]
+    assert torch.equal(a, b)                                                    # shift equivariance in the interior
+    # oracle on a crop: outputs [40:56, 60:76, 100:116] only see inputs [39:57, 59:77, 99:117]
+    xc = x[:, 39:57, 59:77, 99:117].float().permute(0, 4, 1, 2, 3).cpu()
+    ref = O.conv(xc, bf(w.cpu()), None, padding=0)
+    got = y[:, 40:56, 60:76, 100:116, :64].permute(0, 4, 1, 2, 3).cpu()
+    assert rel_err(got, ref) < 1e-2
+
+
+def test_full_size_posterior_properties(dev):
+    """2 097 152 voxels, K = 14 (config C3): at t = 1 the fused kernel returns argmax of the UNet probabilities; labels are
+    in range; the Philox race is reproducible and its label histogram follows the mean posterior."""
+    from jointimagegeneration_amd import ops
+    K, M = 14, 128 ** 3
+    g = torch.Generator(device=dev).manual_seed(5)
+    logits = 2 * torch.randn(M, 32, generator=g, device=dev)
+    lab = torch.randint(0, K, (M,), generator=g, device=dev, dtype=torch.int32)
+    one = torch.tensor([0.0, 1.0], device=dev)                                  # t == 1: a = 0, abar = 1
+    out = ops.ccdm_posterior_sample(logits, True, lab, one, K, draw=False)
+    assert torch.equal(out.long(), logits[:, :K].argmax(-1))
+    sc = torch.tensor([0.97, 0.6], device=dev)
+    off = torch.tensor([123], dtype=torch.int64, device=dev)
+    probs = torch.empty(M, K, device=dev)
+    a = ops.ccdm_posterior_sample(logits, True, lab, sc, K, philox_seed=9, philox_offset=off, draw=True, probs_out=probs)
+    b = ops.ccdm_posterior_sample(logits, True, lab, sc, K, philox_seed=9, philox_offset=off, draw=True)
+    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < K
+    assert torch.allclose(probs.sum(-1), torch.ones(M, device=dev), atol=1e-5)
+    freq = torch.bincount(a.long(), minlength=K).float() / M
+    assert float((freq - probs.mean(0)).abs().max()) < 2e-3
