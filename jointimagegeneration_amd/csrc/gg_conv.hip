@@ -310,12 +310,14 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
     constexpr int BM = 64, CPS = 5;
     constexpr int XT = BM * 64, WT = 32 * 64;                       // one 32-channel tile of X / W in LDS
     constexpr int STAGE = CPS * (XT + WT);                           // 30 KiB
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int GNMAX = 2560;                                      // max C1+C2 with a fused prologue (scale+shift staged in LDS)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (PRO ? 2 * GNMAX * 4 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const long long m0 = (long long)blockIdx.x * BM;
     const int g0 = blockIdx.y;
+    float *gns = reinterpret_cast<float *>(smem + 2 * STAGE);       // [C] scale then [C] shift of this block's sample
 
     // gather duty: row tid>>2, 16-byte slot tid&3 of each of the 5 chunks
     const int xrow = tid >> 2, xq = tid & 3;
@@ -343,6 +345,14 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
     const unsigned limD = (unsigned)(p.D << upD), limH = (unsigned)(p.H << upHW), limW = (unsigned)(p.W << upHW);
     const int gnC = p.C1 + p.C2;
 
+    if (PRO) {   // host guarantees: all rows of a block belong to one sample (Do*Ho*Wo % 64 == 0) and C1+C2 <= GNMAX
+        const int nblk = (int)((unsigned)m0 / osp);
+        for (int i = tid; i < gnC; i += 256) {
+            gns[i] = p.gn_scale[(long long)nblk * gnC + i];
+            gns[GNMAX + i] = p.gn_shift[(long long)nblk * gnC + i];
+        }
+        __syncthreads();
+    }
     // k-steps: (group of 5 chunks) outer, tap inner
     const int ngrp = p.nchunk / CPS, ngrp1 = p.nchunk1 / CPS;
     const int KS_all = ngrp * p.ntaps;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
             const bf16_t *src = (second ? rb2 : rb1) + (pos * (unsigned)Cs + (unsigned)coff);
 #pragma unroll
             for (int c = 0; c < CPS; ++c) xr[c] = *reinterpret_cast<const u32x4 *>(src + c * 32);
-            so = bn * gnC + grp * (CPS * 32) + xq * 8;
+            so = grp * (CPS * 32) + xq * 8;
         }
         // 5 consecutive packed tiles (chunks 5*grp..5*grp+4 of this tap): 10 KiB contiguous
         const bf16_t *wsrc = p.weight + ((((long long)g0 * p.ntaps + tap) * p.nchunk + grp * CPS) << 10);
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
         for (int c = 0; c < CPS; ++c) {
             u32x4 v = xr[c];
             if (PRO && so >= 0) {
-                const float *sc = p.gn_scale + so + c * 32, *sh = p.gn_shift + so + c * 32;
+                const float *sc = gns + so + c * 32, *sh = gns + GNMAX + so + c * 32;
                 f32x4 s0 = *reinterpret_cast<const f32x4 *>(sc), s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
                 f32x4 h0 = *reinterpret_cast<const f32x4 *>(sh), h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
                 bf16x8 xb8 = __builtin_bit_cast(bf16x8, v), yb;
@@ -660,7 +670,11 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
     if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32) return 0;
     ConvParams p;
     fill_params(d, p);
-    return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK ? 1 : 0;
+    if (gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK) return 1;
+    static const int g5_fuse = [] { const char *e = getenv("GG_G5_FUSE"); return e ? atoi(e) : 0; }();
+    if (!g5_fuse || gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, 1)) return 0;
+    const long long osp = (long long)d->Do * d->Ho * d->Wo;
+    return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) && osp % 64 == 0 && d->C1 + d->C2 <= 2560) ? 1 : 0;
 }
 
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
@@ -723,6 +737,8 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
         }
         p.splitk = s5;
         dim3 grid((unsigned)((p.M + 63) / 64), (unsigned)(p.Cout_pad / 32), (unsigned)s5);
+        if (p.prologue_act && (((long long)p.Do * p.Ho * p.Wo) % 64 || p.C1 + p.C2 > 2560))
+            GG_FAIL(GG_ERR_UNSUPPORTED, "conv: fused prologue on the 160-step kernel needs Do*Ho*Wo %% 64 == 0 and C <= 2560");
         if (p.prologue_act) hipLaunchKernelGGL(conv_gather5_kernel<1>, grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(conv_gather5_kernel<0>, grid, dim3(256), 0, stream, p);
         GG_CHECK_LAUNCH();

@@ -187,7 +187,7 @@ def test_conv_gather5_two_source_prologue_residual(dev):
     """160-channel-step gather variant (channel counts that are multiples of 160): fused concat, GN prologue, residual, split-K."""
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(8)
-    N, C1, C2, Cout, sp = 1, 320, 160, 160, (24, 20)
+    N, C1, C2, Cout, sp = 1, 320, 160, 160, (32, 16)
     x1, x2 = torch.randn((N, C1) + sp, generator=g), torch.randn((N, C2) + sp, generator=g)
     w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)
     b = torch.randn(Cout, generator=g) * 0.1
