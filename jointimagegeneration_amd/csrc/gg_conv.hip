@@ -572,6 +572,9 @@ extern "C" int gg_conv_pack_weight(const float *w, int32_t Cout, int32_t Cin, in
 
 // halo fast path (gg_conv_halo.hip); returns GG_ERR_UNSUPPORTED when the shape is outside its envelope
 int gg_conv_halo_try(const ConvParams &p, hipStream_t stream);
+// box-resident 2-D path for under-filled grids (gg_conv_box.hip); same contract as gg_conv_halo_try
+int gg_conv_box_try(const ConvParams &p, hipStream_t stream);
+bool gg_conv_box_fuses_prologue(const ConvParams &p);
 // tiny-M weight-streaming path (gg_conv_tiny.hip): plan returns 0 (not applicable) or the K split
 int gg_conv_tiny_plan(long long M, int Cout_pad, int KS, int prologue_act);
 int gg_conv_tiny_launch(const ConvParams &p, hipStream_t stream);
@@ -671,6 +674,7 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
     ConvParams p;
     fill_params(d, p);
     if (gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK) return 1;
+    if (gg_conv_box_try(p, (hipStream_t)-1) == GG_OK) return gg_conv_box_fuses_prologue(p) ? 1 : 0;
     static const int g5_fuse = [] { const char *e = getenv("GG_G5_FUSE"); return e ? atoi(e) : 0; }();
     if (!g5_fuse || gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, 1)) return 0;
     const long long osp = (long long)d->Do * d->Ho * d->Wo;
@@ -709,6 +713,8 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
         GG_FAIL(GG_ERR_UNSUPPORTED, "conv: tensor too large for 32-bit in-sample offsets");
 
     int rc = gg_conv_halo_try(p, stream);
+    if (rc != GG_ERR_UNSUPPORTED) return rc;
+    rc = gg_conv_box_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;
 
     if (int tsk = gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, p.prologue_act)) {

@@ -1,0 +1,345 @@
+// Box-resident 2-D convolution for UNDER-FILLED grids (latent UNet levels at batch 1: 64x64 .. 16x16, 160..1280 channels):
+// 3x3, stride 1, pad 1, optional fused nearest x2 upsample, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//
+// These layers are 1-8 GFLOP each: neither MFMA nor HBM bound, but bound by what ONE CU can take in (measured 50-70 GB/s
+// per CU from L2, MI355X_MICROARCH.md "Indexed rows") and by exposed round trips.  The kernel therefore (a) moves the
+// minimum number of bytes into each CU, (b) has every byte in flight at once, and (c) has no barrier in its main loop:
+//   * a workgroup (8 waves) owns TH x 16 output positions x 16*CT output channels; the plan (plan_box) picks TH and CT so
+//     that max-over-CUs of (weight slice + input box) bytes is smallest for a single round of <= 256 workgroups;
+//   * the input box the 9 taps touch ((TH+2) x 18 rows; upsample: (TH/2+2) x 10) is staged into LDS ONCE for ALL input
+//     channels of a stage (<= 128 KiB; two-source concat and zero padding applied here) as one swizzled 64-byte-row plane
+//     per 32-channel chunk.  Every 16-row block of a plane is one global_load_lds wave instruction: the whole box is in
+//     flight at once and costs no VGPRs.  GroupNorm affine (* SiLU) then runs IN PLACE in LDS, once per staged element,
+//     while the weight stream is still arriving;
+//   * the (tap, chunk) k-steps of the stage are split evenly over the 8 waves.  Each wave streams the weight tiles of ITS
+//     k-steps straight from L2 into VGPRs (ring of 2-3 trips x 4 steps, counted vmcnt; no LDS copy, no redundancy between
+//     waves) and reads the activation operand from the LDS box at a shifted row;
+//   * the partial accumulators of the 8 waves are combined through LDS in a fixed order (deterministic), then bias /
+//     residual / store;
+//   * workgroups are renumbered so that the ones sharing a weight slice (weight-heavy layers) or an input box
+//     (activation-heavy layers) run on the same XCD and hit its L2 (blockIdx round-robins over the 8 XCDs).
+#include "gg_conv.h"
+#include <stdlib.h>
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14), as builtins so that the
+// compiler's own wait-count pass sees them
+#define GG_WAITCNT_IMM(VM) ((((VM) & 15) | (((VM) >> 4) << 14)) | 0x70)
+#define GG_BOX_WAIT_BARRIER(VM) do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(VM)); __builtin_amdgcn_s_barrier(); } while (0)
+#define GG_BOX_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(63)); __builtin_amdgcn_s_barrier(); } while (0)
+
+template <int TH, int CT, int UP>
+__global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
+                                                         const int nch_stage, const int gn_bytes, const int q_major)
+{
+    constexpr int TW = 16, NW = 8;
+    constexpr int NTRIP = CT == 2 ? 2 : 3;            // weight trips (4 k-steps each) kept in flight per wave
+    constexpr int HH = UP ? TH / 2 + 2 : TH + 2;
+    constexpr int HW = UP ? TW / 2 + 2 : TW + 2;
+    constexpr int NROWS = HH * HW;
+    constexpr int NRB = (NROWS + 15) / 16;            // 1 KiB DMA blocks (16 rows) per chunk plane
+    constexpr int PLANE = NRB * 1024;                 // one 32-channel chunk of the box
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float *gns = reinterpret_cast<float *>(smem);     // [nch*32] scale, [nch*32] shift of the stage (fused prologue only)
+    char *box = smem + gn_bytes;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- workgroup -> (position tile, cout tile).  Consecutive hardware ids round-robin over the 8 XCDs; give every XCD a
+    //      contiguous run of virtual ids, then decode them cout-major (a run shares weights) or position-major (shares boxes).
+    const int P = p.N * tiles_h * tiles_w, Q = gridDim.x / P;
+    int v = blockIdx.x;
+    if ((gridDim.x & 7) == 0) v = (v & 7) * (gridDim.x >> 3) + (v >> 3);
+    const int by = q_major ? v / P : v % Q;
+    int t = q_major ? v - by * P : v / Q;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h;
+    const int n = t / tiles_h;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int g = CT == 2 ? by : by >> 1, half = CT == 2 ? 0 : by & 1;
+    const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
+    const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
+
+    f32x4 acc[TH][CT];
+#pragma unroll
+    for (int a = 0; a < TH; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t *wbase = p.weight + ((long long)g * 9 * p.nchunk << 10) + half * 512;
+    const int wl0 = fr * 32 + swz64(fr, fq) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
+
+    // staging duty of a lane inside a 16-row DMA block: row (lane>>2), LDS slot (lane&3)
+    const int lrow = lane >> 2, lslot = lane & 3;
+
+    for (int st = 0; st < nstage; ++st) {
+        const int cbase = st * nch_stage;
+        const int nch = (p.nchunk - cbase < nch_stage) ? p.nchunk - cbase : nch_stage;
+        const int S = 9 * nch;
+        const int s0 = (S * wave) / NW, s1 = (S * (wave + 1)) / NW;
+
+        // GroupNorm scale/shift rows of the stage -> LDS, by DMA as well (256 floats per wave instruction)
+        if (p.prologue_act) {
+            const int gn_units = 2 * ((nch + 7) >> 3);
+            for (int u = wave; u < gn_units; u += NW) {
+                const int which = u & 1, blk = u >> 1;
+                const float *gsrc = (which ? p.gn_shift : p.gn_scale) + (long long)n * (p.C1 + p.C2) + cbase * 32 + blk * 256 + lane * 4;
+                if (blk * 256 + lane * 4 < nch * 32)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                                     (__attribute__((address_space(3))) void *)(gns + which * nch * 32 + blk * 256), 16, 0, 0);
+            }
+        }
+        // ---- stage the box of this stage's channels (global_load_lds, everything in flight); padding rows are zeros
+        const int nunit = nch * NRB;
+#pragma unroll 1
+        for (int unit = wave; unit < nunit; unit += NW) {
+            const int c = unit / NRB, rbk = unit - c * NRB;
+            const int row = rbk * 16 + lrow;
+            const int hh = row / HW, hw = row - hh * HW;
+            const int ih = ih0 + hh, iw = iw0 + hw;
+            const int gc = cbase + c;
+            const bool second = gc >= p.nchunk1;
+            const bf16_t *src = second ? p.src2 : p.src1;
+            const int Cs = second ? p.C2 : p.C1;
+            const int q = lslot ^ ((row >> 1) & 2);
+            const int coff = (second ? gc - p.nchunk1 : gc) * 32 + q * 8;
+            char *dst = box + c * PLANE + rbk * 1024;
+            if (row < NROWS) {
+                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                    const bf16_t *sp = src + ((long long)((n * p.H + ih) * p.W + iw)) * Cs + coff;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sp,
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                } else {
+                    *reinterpret_cast<u32x4 *>(dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        // ---- weight stream of this wave: steps s in [s0, s1), s = tap * nch + c.  Loads past the end re-read the last tile
+        //      (unconditional, branch-free: the vmcnt counts stay exact).  Issued AFTER the box so the box lands first.
+        int ltap = s0 / nch, lc = s0 - ltap * nch, lidx = s0;          // load iterator
+        bf16x8 wr[NTRIP][4][CT];
+        auto load_w = [&](bf16x8 (&a)[4][CT]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16_t *tile = wbase + (((long long)ltap * p.nchunk + cbase + lc) << 10) + wl0;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                const int adv = (lidx + 1 < s1) ? 1 : 0;
+                lidx += adv;
+                lc += adv;
+                const int wrap = (lc == nch) ? 1 : 0;
+                lc = wrap ? 0 : lc;
+                ltap += wrap;
+            }
+        };
+        asm volatile("" ::: "memory");                 // keep the weight loads behind the DMA issue
+#pragma unroll
+        for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
+        // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
+        if (NTRIP * 4 * CT == 16) GG_BOX_WAIT_BARRIER(16); else GG_BOX_WAIT_BARRIER(12);
+
+        if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
+#pragma unroll 2
+            for (int unit = wave; unit < nunit; unit += NW) {
+                const int c = unit / NRB, rbk = unit - c * NRB;
+                const int row = rbk * 16 + lrow;
+                const int hh = row / HW, hw = row - hh * HW;
+                const int ih = ih0 + hh, iw = iw0 + hw;
+                if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                    const int q = lslot ^ ((row >> 1) & 2);
+                    char *pc = box + c * PLANE + rbk * 1024 + lane * 16;
+                    const float *sc = gns + c * 32 + q * 8, *sh = sc + nch * 32;
+                    const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sc), sc1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+                    const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sh), sh1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+                    bf16x8 xb = *reinterpret_cast<const bf16x8 *>(pc), yb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y0 = (float)xb[e] * sc0[e] + sh0[e], y1 = (float)xb[e + 4] * sc1[e] + sh1[e];
+                        if (p.prologue_act == 1) {
+                            y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                            y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                        }
+                        yb[e] = (bf16_t)y0;
+                        yb[e + 4] = (bf16_t)y1;
+                    }
+                    *reinterpret_cast<bf16x8 *>(pc) = yb;
+                }
+            }
+            GG_BOX_LDS_BARRIER();
+        }
+
+        // ---- this wave's k-steps: 4 per trip
+        int ctap = s0 / nch, cc = s0 - ctap * nch;          // compute iterator
+        auto trip = [&](const bf16x8 (&a)[4][CT], int s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s + u < s1) {
+                    const int kh = ctap / 3, kw = ctap - kh * 3;
+                    const char *plane = box + cc * PLANE;
+                    const int rwk = UP ? ((fr + kw + 1) >> 1) : (fr + kw);     // per-lane part of the operand row
+                    bf16x8 xf[TH];
+#pragma unroll
+                    for (int tt = 0; tt < TH; ++tt) {
+                        const int hh = UP ? ((tt + kh + 1) >> 1) : tt + kh;
+                        const int row = hh * HW + rwk;
+                        xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < TH; ++tt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][ct], xf[tt], acc[tt][ct], 0, 0, 0);
+                    if (++cc == nch) { cc = 0; ++ctap; }
+                }
+            }
+        };
+        int s = s0;
+#pragma unroll 1
+        for (; s + 4 * NTRIP < s1; s += 4 * NTRIP) {       // steady state: at least one of the refilled trips is real
+#pragma unroll
+            for (int r = 0; r < NTRIP; ++r) {
+                trip(wr[r], s + 4 * r);
+                load_w(wr[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NTRIP; ++r) trip(wr[r], s + 4 * r);      // drain: nothing left to load
+        GG_BOX_WAIT_BARRIER(0);   // all waves done with the box: it may be overwritten (next stage / the reduction area)
+    }
+
+    // ---- combine the 8 waves (fixed order), then bias / residual / store.  red[wave][tt][ct][lane] is lane-contiguous:
+    //      conflict-free 1 KiB wave writes and reads.
+    f32x4 *red = reinterpret_cast<f32x4 *>(box);
+#pragma unroll
+    for (int tt = 0; tt < TH; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) red[((wave * TH + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
+    GG_BOX_LDS_BARRIER();
+    const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
+    for (int i = tid; i < TH * CT * 64; i += 512) {
+        f32x4 a = red[i];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) a += red[w * TH * CT * 64 + i];
+        const int l = i & 63, ct = (i >> 6) % CT, tt = (i >> 6) / CT;
+        const int co = g * 32 + half * 16 + ct * 16 + (l >> 4) * 4;
+        if (brow) a += *reinterpret_cast<const f32x4 *>(brow + co);
+        const long long mo = ((long long)n * p.Ho + (h0 + tt)) * p.Wo + (w0 + (l & 15));
+        const long long o = mo * p.Cout_pad + co;
+        if (p.residual) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += (float)r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (co + j >= p.Cout) a[j] = 0.f;
+        if (p.out_dtype == GG_F32) {
+            *reinterpret_cast<f32x4 *>((float *)p.out + o) = a;
+        } else {
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)a[j];
+            *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+        }
+    }
+}
+
+struct BoxPlan { int TH, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; };
+
+// Cost model: bytes one CU has to take in (its weight slice + its input box), times the number of rounds the grid needs on
+// 256 CUs.  Smallest wins; ties go to the larger tile (fewer redundant halo bytes overall).
+static bool plan_box(const ConvParams &p, BoxPlan &pl)
+{
+    static const int enabled = [] { const char *e = getenv("GG_BOX2D"); return e ? atoi(e) : 1; }();
+    static const long long max_blocks = [] { const char *e = getenv("GG_BOX2D_MAXBLK"); return e ? atoll(e) : 1024LL; }();
+    static const long long lds_cap = [] { const char *e = getenv("GG_BOX2D_LDS"); return e ? atoll(e) : 131072LL; }();
+    static const int force_th = [] { const char *e = getenv("GG_BOX2D_TH"); return e ? atoi(e) : 0; }();
+    static const int force_ct = [] { const char *e = getenv("GG_BOX2D_CT"); return e ? atoi(e) : 0; }();
+    if (!enabled) return false;
+    if (!(p.kd == 1 && p.kh == 3 && p.kw == 3 && p.D == 1 && p.stride == 1 && p.pad == 1)) return false;
+    if (p.Wo % 16) return false;
+    const long long wbytes16 = 16LL * 9 * p.nchunk * 32 * 2;        // weight slice of 16 output channels
+    double best = 0;
+    int bTH = 0, bCT = 0;
+    for (int TH : {8, 4, 2}) {
+        if (p.Ho % TH || (force_th && TH != force_th)) continue;
+        const int rows = p.upsample ? (TH / 2 + 2) * 10 : (TH + 2) * 18;
+        const long long boxb = (long long)rows * p.nchunk * 64;
+        for (int CT : {2, 1}) {
+            if (force_ct && CT != force_ct) continue;
+            const long long blocks = (long long)p.N * (p.Ho / TH) * (p.Wo / 16) * (p.Cout_pad / (16 * CT));
+            if (blocks > max_blocks) continue;
+            const double cost = (double)(wbytes16 * CT + boxb) * (double)((blocks + 255) / 256);
+            if (!bTH || cost < best * 0.97) { best = cost; bTH = TH; bCT = CT; }
+        }
+    }
+    if (!bTH) return false;                                          // filled grids: the halo / wide-tile kernels win
+    const int TH = bTH, CT = bCT;
+    const int rows = p.upsample ? (TH / 2 + 2) * 10 : (TH + 2) * 18;
+    const long long plane = (long long)((rows + 15) / 16) * 1024;   // whole 16-row DMA blocks
+    long long cap = lds_cap / plane;
+    if (cap < 1) return false;
+    const int nstage = (int)((p.nchunk + cap - 1) / cap);
+    const int nch_stage = (p.nchunk + nstage - 1) / nstage;
+    long long smem = nch_stage * plane;
+    const long long red = 8LL * TH * CT * 64 * 16;                   // [wave][tt][ct][lane] f32x4
+    if (smem < red) smem = red;
+    const int gn_bytes = p.prologue_act ? (nch_stage * 32 * 8 + 1023) / 1024 * 1024 : 0;
+    // XCD locality: a run of workgroups shares weights (cout-major) when the weights are the bigger re-fetch, else boxes
+    const long long P = (long long)p.N * (p.Ho / TH) * (p.Wo / 16), Q = p.Cout_pad / (16 * CT);
+    const long long wtot = wbytes16 * (p.Cout_pad / 16), xtot = (long long)p.N * p.H * p.W * p.nchunk * 64;
+    const long long cost_q = wtot + xtot * (Q < 8 ? Q : 8), cost_p = wtot * (P < 8 ? P : 8) + xtot;
+    pl = {TH, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes};
+    return true;
+}
+
+template <int TH, int CT, int UP>
+static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TH, CT, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return GG_ERR_UNSUPPORTED;
+        attr_set = true;
+    }
+    const int tiles_h = p.Ho / TH, tiles_w = p.Wo / 16;
+    dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
+    hipLaunchKernelGGL((conv_box2d_kernel<TH, CT, UP>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage, pl.nch_stage,
+                       pl.gn_bytes, pl.q_major);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+template <int UP>
+static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
+{
+    switch (pl.TH * 10 + pl.CT) {
+        case 82: return launch_box<8, 2, UP>(p, pl, stream);
+        case 81: return launch_box<8, 1, UP>(p, pl, stream);
+        case 42: return launch_box<4, 2, UP>(p, pl, stream);
+        case 41: return launch_box<4, 1, UP>(p, pl, stream);
+        case 22: return launch_box<2, 2, UP>(p, pl, stream);
+        default: return launch_box<2, 1, UP>(p, pl, stream);
+    }
+}
+
+// The in-place prologue activates the whole box once per workgroup, i.e. once per cout tile: with Q cout tiles it is Q x 1.4
+// times the work of a separate GroupNorm-apply launch, and transcendental-bound (2 per element).  Fusing pays only when few
+// cout tiles share a box (measured: Q = 5 breaks even with the 3 us apply launch, Q = 20 costs +6 us).
+bool gg_conv_box_fuses_prologue(const ConvParams &p)
+{
+    static const int fuse_q = [] { const char *e = getenv("GG_BOX2D_FUSE_Q"); return e ? atoi(e) : 2; }();
+    BoxPlan pl;
+    if (!plan_box(p, pl)) return false;
+    return p.Cout_pad / (16 * pl.CT) <= fuse_q;
+}
+
+// Returns GG_ERR_UNSUPPORTED (silently) when the shape is outside the envelope.  stream == (hipStream_t)-1: dry run.
+int gg_conv_box_try(const ConvParams &p, hipStream_t stream)
+{
+    BoxPlan pl;
+    if (!plan_box(p, pl)) return GG_ERR_UNSUPPORTED;
+    if (stream == (hipStream_t)-1) return GG_OK;
+    return p.upsample ? dispatch_box<1>(p, pl, stream) : dispatch_box<0>(p, pl, stream);
+}

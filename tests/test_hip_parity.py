@@ -168,7 +168,7 @@ def test_splitk_in_launch_combine_is_bit_identical_and_self_cleaning(dev):
     consumer's caches warm, and must leave the ticket buffer zero."""
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(12)
-    for (N, Cin, Cout, sp) in ((1, 1600, 800, (4, 4)), (1, 160, 160, (64, 64)), (2, 640, 320, (16, 16))):
+    for (N, Cin, Cout, sp) in ((1, 1600, 800, (4, 4)), (1, 320, 160, (20, 20)), (2, 640, 320, (12, 12))):
         x = ops.to_cl(torch.randn((N, Cin) + sp, generator=g).to(dev))
         w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
         res = ops.to_cl(torch.randn((N, Cout) + sp, generator=g).to(dev))
@@ -187,7 +187,7 @@ def test_conv_gather5_two_source_prologue_residual(dev):
     """160-channel-step gather variant (channel counts that are multiples of 160): fused concat, GN prologue, residual, split-K."""
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(8)
-    N, C1, C2, Cout, sp = 1, 320, 160, 160, (32, 16)
+    N, C1, C2, Cout, sp = 1, 320, 160, 160, (24, 8)           # W % 16 != 0: outside the halo / box kernels' envelope
     x1, x2 = torch.randn((N, C1) + sp, generator=g), torch.randn((N, C2) + sp, generator=g)
     w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -211,6 +211,68 @@ def test_conv_gather5_two_source_prologue_residual(dev):
     w2 = torch.randn(160, 160, 3, 3, generator=g) / math.sqrt(160 * 9)
     o = ops.conv(ops.to_cl(xs.to(dev)), ops.pack_conv_weight(w2.to(dev), 160), None, 160, k=(1, 3, 3), stride=2, pad=1)
     assert rel_err(ops.from_cl(o, 2), O.conv(bf(xs), bf(w2), stride=2, padding=1)) < 1e-2
+
+
+BOX_CASES = [
+    # name, N, Cin, Cout, spatial(in), upsample   (2-D 3x3 s1 p1, W % 16 == 0, H % 32 != 0: the halo kernel declines,
+    # the box-resident kernel takes them; TH = rows of 16 positions per workgroup follows from the grid size)
+    ("box_th2", 1, 160, 160, (16, 16), False),
+    ("box_th4", 2, 32, 512, (20, 16), False),
+    ("box_th8", 2, 64, 320, (48, 32), False),
+    ("box_th2_up", 1, 96, 64, (8, 8), True),
+    ("box_th8_up", 2, 32, 320, (24, 16), True),
+    ("box_cout14_f32", 1, 64, 14, (16, 32), False),
+    ("box_cin15", 1, 15, 64, (12, 16), False),
+]
+
+
+@pytest.mark.parametrize("case", BOX_CASES, ids=[c[0] for c in BOX_CASES])
+def test_conv_box_kernel_matches_oracle(dev, case):
+    from jointimagegeneration_amd import ops
+    name, N, Cin, Cout, sp, up = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn((N, Cin) + sp, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = O.conv(O.upsample_nearest2(bf(x)) if up else bf(x), bf(w), b, padding=1)
+    xcl = ops.to_cl(x.to(dev))
+    pw = ops.pack_conv_weight(w.to(dev), xcl.Cpad)
+    out = ops.conv(xcl, pw, ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1, 3, 3), upsample=up, out_f32=(Cout == 14))
+    got = ops.from_cl(out, 2).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-2, rel_err(got, ref)
+    if out.Cpad > Cout:
+        assert float(out.t[..., Cout:].float().abs().max()) == 0.0
+
+
+def test_conv_box_two_source_prologue_residual_two_stages(dev):
+    """Box kernel with everything fused: concat of two sources, GroupNorm(*SiLU) prologue, per-sample bias, residual; 1280 input
+    channels do not fit one LDS stage, so the box is staged twice."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, C1, C2, Cout, sp = 2, 640, 640, 64, (16, 16)
+    x1, x2 = torch.randn((N, C1) + sp, generator=g), torch.randn((N, C2) + sp, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)
+    tb = torch.randn(N, Cout, generator=g)
+    res = torch.randn((N, Cout) + sp, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C1 + C2, generator=g), 0.1 * torch.randn(C1 + C2, generator=g)
+    xc = torch.cat([bf(x1), bf(x2)], 1)
+    c1, c2 = ops.to_cl(x1.to(dev)), ops.to_cl(x2.to(dev))
+    scale, shift = ops.groupnorm_stats(c1, gamma.to(dev), beta.to(dev), 1e-5, src2=c2)
+    pw = ops.pack_conv_weight(w.to(dev), C1 + C2)
+    tbp = torch.zeros(N, ops.pad32(Cout), device=dev); tbp[:, :Cout] = tb.to(dev)
+    assert ops.conv_fuses_prologue(c1, Cout, k=(1, 3, 3), src2=c2)
+    for silu in (True, False):
+        a = O.group_norm(xc, gamma, beta, 1e-5)
+        a = O.silu(a) if silu else a
+        ref = O.conv(bf(a), bf(w), None, padding=1) + tb[:, :, None, None] + bf(res)
+        out = ops.conv(c1, pw, tbp, Cout, k=(1, 3, 3), src2=c2, residual=ops.to_cl(res.to(dev)), bias_per_sample=True,
+                       prologue=(scale, shift), prologue_silu=silu)
+        assert rel_err(ops.from_cl(out, 2), ref) < 1.5e-2
+    # determinism: the 4-wave combine has a fixed order
+    o1 = ops.conv(c1, pw, tbp, Cout, k=(1, 3, 3), src2=c2, bias_per_sample=True).t
+    o2 = ops.conv(c1, pw, tbp, Cout, k=(1, 3, 3), src2=c2, bias_per_sample=True).t
+    assert torch.equal(o1, o2)
 
 
 def test_conv_rejects_bad_shapes(dev):

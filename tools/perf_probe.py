@@ -39,6 +39,9 @@ for w in which:
             x = CL(torch.randn(N, 1, R, R, 32, device=dev).bfloat16(), 8)
             row = u.time_bias_rows(torch.full((N,), 981.0, device=dev))
             t = timeit(lambda: u.forward_cl(x, row), n=5)
+            if os.environ.get("GG_NO_GRAPH"):
+                print(f"LDM UNet N={N} {R}^2 forward: eager {t*1e3:.2f} ms")
+                continue
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 u.forward_cl(x, row)

@@ -12,6 +12,13 @@ w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
 pw = ops.pack_conv_weight(w, Cin)
 pb = ops.pad_bias(None, Cout, dev)
 f = lambda: ops.conv(x, pw, pb, Cout, k=(1, k, k), pad=k // 2)
+if os.environ.get("PROBE_PRO"):      # GroupNorm*SiLU in front of the conv: fused prologue when the kernel takes it, else apply + conv
+    gamma, beta = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    sc, sh = ops.groupnorm_stats(x, gamma, beta, 1e-5)
+    if ops.conv_fuses_prologue(x, Cout, k=(1, k, k), pad=k // 2):
+        f = lambda: ops.conv(x, pw, pb, Cout, k=(1, k, k), pad=k // 2, prologue=(sc, sh))
+    else:
+        f = lambda: ops.conv(ops.groupnorm_apply(x, sc, sh, True), pw, pb, Cout, k=(1, k, k), pad=k // 2)
 f(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
@@ -22,4 +29,4 @@ for _ in range(5): g.replay()
 torch.cuda.synchronize()
 t = (time.time() - t0) / 250
 gf = 2.0 * N * H * W * Cout * Cin * k * k / 1e9
-print(f"conv N={N} {Cin}->{Cout} {H}x{W} k={k}: {t*1e6:.1f} us/conv ({gf/t/1e3:.1f} TFLOP/s) env SPLITK_TARGET={os.environ.get('GG_SPLITK_TARGET')}")
+print(f"conv N={N} {Cin}->{Cout} {H}x{W} k={k}: {t*1e6:.1f} us/conv ({gf/t/1e3:.1f} TFLOP/s) pro={os.environ.get('PROBE_PRO')} box={os.environ.get('GG_BOX2D')} minblk={os.environ.get('GG_BOX2D_MINBLK')}")
