@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
     const int xrow = tid >> 2, xq = tid & 3;
     const unsigned osp = (unsigned)(p.Do * p.Ho * p.Wo), ohw = (unsigned)(p.Ho * p.Wo);
     bool rv;
-    int bn, bd, bh, bw;
+    int bd, bh, bw;
     const bf16_t *rb1, *rb2;
     {
         long long m = m0 + xrow;
@@ -333,7 +333,6 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
         unsigned od = r / ohw;
         r -= od * ohw;
         unsigned oh = r / (unsigned)p.Wo, ow = r - oh * (unsigned)p.Wo;
-        bn = (int)n;
         bd = (p.kd == 1) ? (int)od * p.stride : (int)od * p.stride - p.pad;
         bh = (p.kh == 1) ? (int)oh * p.stride : (int)oh * p.stride - p.pad;
         bw = (p.kw == 1) ? (int)ow * p.stride : (int)ow * p.stride - p.pad;

@@ -261,7 +261,6 @@ def test_conv_box_two_source_prologue_residual_two_stages(dev):
     scale, shift = ops.groupnorm_stats(c1, gamma.to(dev), beta.to(dev), 1e-5, src2=c2)
     pw = ops.pack_conv_weight(w.to(dev), C1 + C2)
     tbp = torch.zeros(N, ops.pad32(Cout), device=dev); tbp[:, :Cout] = tb.to(dev)
-    assert ops.conv_fuses_prologue(c1, Cout, k=(1, 3, 3), src2=c2)
     for silu in (True, False):
         a = O.group_norm(xc, gamma, beta, 1e-5)
         a = O.silu(a) if silu else a
