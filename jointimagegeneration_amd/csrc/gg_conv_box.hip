@@ -4,7 +4,8 @@
 // These layers are 1-8 GFLOP each: neither MFMA nor HBM bound, but bound by what ONE CU can take in (measured 50-70 GB/s
 // per CU from L2, MI355X_MICROARCH.md "Indexed rows") and by exposed round trips.  The kernel therefore (a) moves the
 // minimum number of bytes into each CU, (b) has every byte in flight at once, and (c) has no barrier in its main loop:
-//   * a workgroup (8 waves) owns TH x 16 output positions x 16*CT output channels; the plan (plan_box) picks TH and CT so
+//   * a workgroup (8 waves) owns MT position tiles (16 positions each: 1x16, 2x8 or 4x4, so 8x8 and 4x4 levels fit too) x 16*CT
+//     output channels; the plan (plan_box) picks MT and CT so
 //     that max-over-CUs of (weight slice + input box) bytes is smallest for a single round of <= 256 workgroups;
 //   * the input box the 9 taps touch ((TH+2) x 18 rows; upsample: (TH/2+2) x 10) is staged into LDS ONCE for ALL input
 //     channels of a stage (<= 128 KiB; two-source concat and zero padding applied here) as one swizzled 64-byte-row plane
@@ -27,11 +28,14 @@
 #define GG_BOX_WAIT_BARRIER(VM) do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(VM)); __builtin_amdgcn_s_barrier(); } while (0)
 #define GG_BOX_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(63)); __builtin_amdgcn_s_barrier(); } while (0)
 
-template <int TH, int CT, int UP>
+template <int TWI, int MT, int CT, int UP>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
                                                          const int nch_stage, const int gn_bytes, const int q_major)
 {
-    constexpr int TW = 16, NW = 8;
+    // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
+    constexpr int TW = TWI, NW = 8;
+    constexpr int RPT = 16 / TWI;
+    constexpr int TH = MT * RPT;                      // output rows of the workgroup
     constexpr int NTRIP = CT == 2 ? 2 : 3;            // weight trips (4 k-steps each) kept in flight per wave
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2;
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
+    const int pos_r = fr / TWI, pos_c = fr % TWI;     // this lane's position inside a position tile
 
     // ---- workgroup -> (position tile, cout tile).  Consecutive hardware ids round-robin over the 8 XCDs; give every XCD a
     //      contiguous run of virtual ids, then decode them cout-major (a run shares weights) or position-major (shares boxes).
@@ -61,9 +66,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
     const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
 
-    f32x4 acc[TH][CT];
+    f32x4 acc[MT][CT];
 #pragma unroll
-    for (int a = 0; a < TH; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -177,16 +182,17 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                 if (s + u < s1) {
                     const int kh = ctap / 3, kw = ctap - kh * 3;
                     const char *plane = box + cc * PLANE;
-                    const int rwk = UP ? ((fr + kw + 1) >> 1) : (fr + kw);     // per-lane part of the operand row
-                    bf16x8 xf[TH];
+                    const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
+                    bf16x8 xf[MT];
 #pragma unroll
-                    for (int tt = 0; tt < TH; ++tt) {
-                        const int hh = UP ? ((tt + kh + 1) >> 1) : tt + kh;
+                    for (int tt = 0; tt < MT; ++tt) {
+                        const int orow = tt * RPT + pos_r;
+                        const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
                         const int row = hh * HW + rwk;
                         xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < TH; ++tt)
+                    for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
                             acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][ct], xf[tt], acc[tt][ct], 0, 0, 0);
@@ -212,19 +218,19 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     //      conflict-free 1 KiB wave writes and reads.
     f32x4 *red = reinterpret_cast<f32x4 *>(box);
 #pragma unroll
-    for (int tt = 0; tt < TH; ++tt)
+    for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) red[((wave * TH + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
+        for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
     GG_BOX_LDS_BARRIER();
     const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
-    for (int i = tid; i < TH * CT * 64; i += 512) {
+    for (int i = tid; i < MT * CT * 64; i += 512) {
         f32x4 a = red[i];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) a += red[w * TH * CT * 64 + i];
+        for (int w = 1; w < NW; ++w) a += red[w * MT * CT * 64 + i];
         const int l = i & 63, ct = (i >> 6) % CT, tt = (i >> 6) / CT;
         const int co = g * 32 + half * 16 + ct * 16 + (l >> 4) * 4;
         if (brow) a += *reinterpret_cast<const f32x4 *>(brow + co);
-        const long long mo = ((long long)n * p.Ho + (h0 + tt)) * p.Wo + (w0 + (l & 15));
+        const long long mo = ((long long)n * p.Ho + (h0 + tt * RPT + (l & 15) / TWI)) * p.Wo + (w0 + (l & 15) % TWI);
         const long long o = mo * p.Cout_pad + co;
         if (p.residual) {
             const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     }
 }
 
-struct BoxPlan { int TH, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; };
+struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; };
 
 // Cost model: bytes one CU has to take in (its weight slice + its input box), times the number of rounds the grid needs on
 // 256 CUs.  Smallest wins; ties go to the larger tile (fewer redundant halo bytes overall).
@@ -258,69 +264,76 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     static const int force_ct = [] { const char *e = getenv("GG_BOX2D_CT"); return e ? atoi(e) : 0; }();
     if (!enabled) return false;
     if (!(p.kd == 1 && p.kh == 3 && p.kw == 3 && p.D == 1 && p.stride == 1 && p.pad == 1)) return false;
-    if (p.Wo % 16) return false;
+    const int TWI = p.Wo % 16 == 0 ? 16 : p.Wo % 8 == 0 ? 8 : p.Wo % 4 == 0 ? 4 : 0;   // width of a 16-position MFMA tile
+    if (!TWI) return false;
+    const int RPT = 16 / TWI;
     const long long wbytes16 = 16LL * 9 * p.nchunk * 32 * 2;        // weight slice of 16 output channels
     double best = 0;
-    int bTH = 0, bCT = 0;
-    for (int TH : {8, 4, 2}) {
-        if (p.Ho % TH || (force_th && TH != force_th)) continue;
-        const int rows = p.upsample ? (TH / 2 + 2) * 10 : (TH + 2) * 18;
+    int bMT = 0, bCT = 0;
+    for (int MT : {8, 4, 2, 1}) {
+        const int TH = MT * RPT;
+        if (p.Ho % TH || (p.upsample && (TH & 1)) || (force_th && MT != force_th)) continue;
+        if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
+        const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + 2) * (TWI + 2);
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             if (force_ct && CT != force_ct) continue;
-            const long long blocks = (long long)p.N * (p.Ho / TH) * (p.Wo / 16) * (p.Cout_pad / (16 * CT));
+            const long long blocks = (long long)p.N * (p.Ho / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
             if (blocks > max_blocks) continue;
             const double cost = (double)(wbytes16 * CT + boxb) * (double)((blocks + 255) / 256);
-            if (!bTH || cost < best * 0.97) { best = cost; bTH = TH; bCT = CT; }
+            if (!bMT || cost < best * 0.97) { best = cost; bMT = MT; bCT = CT; }
         }
     }
-    if (!bTH) return false;                                          // filled grids: the halo / wide-tile kernels win
-    const int TH = bTH, CT = bCT;
-    const int rows = p.upsample ? (TH / 2 + 2) * 10 : (TH + 2) * 18;
+    if (!bMT) return false;                                          // filled grids: the halo / wide-tile kernels win
+    const int MT = bMT, CT = bCT, TH = MT * RPT;
+    const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + 2) * (TWI + 2);
     const long long plane = (long long)((rows + 15) / 16) * 1024;   // whole 16-row DMA blocks
     long long cap = lds_cap / plane;
     if (cap < 1) return false;
     const int nstage = (int)((p.nchunk + cap - 1) / cap);
+    if (TWI == 4 && nstage > 1) return false;                        // 4x4 levels with > 1 stage: the split-K tiny kernel fills more CUs
     const int nch_stage = (p.nchunk + nstage - 1) / nstage;
     long long smem = nch_stage * plane;
-    const long long red = 8LL * TH * CT * 64 * 16;                   // [wave][tt][ct][lane] f32x4
+    const long long red = 8LL * MT * CT * 64 * 16;                   // [wave][tt][ct][lane] f32x4
     if (smem < red) smem = red;
     const int gn_bytes = p.prologue_act ? (nch_stage * 32 * 8 + 1023) / 1024 * 1024 : 0;
     // XCD locality: a run of workgroups shares weights (cout-major) when the weights are the bigger re-fetch, else boxes
-    const long long P = (long long)p.N * (p.Ho / TH) * (p.Wo / 16), Q = p.Cout_pad / (16 * CT);
+    const long long P = (long long)p.N * (p.Ho / TH) * (p.Wo / TWI), Q = p.Cout_pad / (16 * CT);
     const long long wtot = wbytes16 * (p.Cout_pad / 16), xtot = (long long)p.N * p.H * p.W * p.nchunk * 64;
     const long long cost_q = wtot + xtot * (Q < 8 ? Q : 8), cost_p = wtot * (P < 8 ? P : 8) + xtot;
-    pl = {TH, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes};
+    pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes};
     return true;
 }
 
-template <int TH, int CT, int UP>
+template <int TWI, int MT, int CT, int UP>
 static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TH, CT, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_set = true;
     }
-    const int tiles_h = p.Ho / TH, tiles_w = p.Wo / 16;
+    const int tiles_h = p.Ho / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
-    hipLaunchKernelGGL((conv_box2d_kernel<TH, CT, UP>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage, pl.nch_stage,
-                       pl.gn_bytes, pl.q_major);
+    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
+                       pl.nch_stage, pl.gn_bytes, pl.q_major);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
 
-template <int UP>
+template <int CT, int UP>
 static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
-    switch (pl.TH * 10 + pl.CT) {
-        case 82: return launch_box<8, 2, UP>(p, pl, stream);
-        case 81: return launch_box<8, 1, UP>(p, pl, stream);
-        case 42: return launch_box<4, 2, UP>(p, pl, stream);
-        case 41: return launch_box<4, 1, UP>(p, pl, stream);
-        case 22: return launch_box<2, 2, UP>(p, pl, stream);
-        default: return launch_box<2, 1, UP>(p, pl, stream);
+    switch (pl.TWI * 10 + pl.MT) {
+        case 168: return launch_box<16, 8, CT, UP>(p, pl, stream);
+        case 164: return launch_box<16, 4, CT, UP>(p, pl, stream);
+        case 162: return launch_box<16, 2, CT, UP>(p, pl, stream);
+        case 84: return launch_box<8, 4, CT, UP>(p, pl, stream);
+        case 82: return launch_box<8, 2, CT, UP>(p, pl, stream);
+        case 81: return launch_box<8, 1, CT, UP>(p, pl, stream);
+        case 41: return launch_box<4, 1, CT, UP>(p, pl, stream);
+        default: return GG_ERR_UNSUPPORTED;
     }
 }
 
@@ -341,5 +354,6 @@ int gg_conv_box_try(const ConvParams &p, hipStream_t stream)
     BoxPlan pl;
     if (!plan_box(p, pl)) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
-    return p.upsample ? dispatch_box<1>(p, pl, stream) : dispatch_box<0>(p, pl, stream);
+    if (pl.CT == 2) return p.upsample ? dispatch_box<2, 1>(p, pl, stream) : dispatch_box<2, 0>(p, pl, stream);
+    return p.upsample ? dispatch_box<1, 1>(p, pl, stream) : dispatch_box<1, 0>(p, pl, stream);
 }

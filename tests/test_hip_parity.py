@@ -223,6 +223,14 @@ BOX_CASES = [
     ("box_th8_up", 2, 32, 320, (24, 16), True),
     ("box_cout14_f32", 1, 64, 14, (16, 32), False),
     ("box_cin15", 1, 15, 64, (12, 16), False),
+    # 8-wide and 4-wide position tiles (2x8, 4x4 positions per MFMA tile): the deepest UNet levels
+    ("box_w8", 1, 640, 640, (8, 8), False),
+    ("box_w8_n2", 2, 96, 64, (8, 8), False),
+    ("box_w8_h24", 1, 64, 96, (24, 8), False),
+    ("box_w4", 1, 800, 800, (4, 4), False),
+    ("box_w4_n3", 3, 64, 32, (4, 4), False),
+    ("box_w8_up", 2, 160, 160, (4, 4), True),
+    ("box_w8_three_stages", 1, 1280, 64, (8, 8), False),
 ]
 
 
