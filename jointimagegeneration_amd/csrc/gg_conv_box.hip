@@ -1,5 +1,5 @@
 // Box-resident 2-D convolution for UNDER-FILLED grids (latent UNet levels at batch 1: 64x64 .. 16x16, 160..1280 channels):
-// 3x3, stride 1, pad 1, optional fused nearest x2 upsample, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+// 3x3 (stride 1, pad 1, optional fused nearest x2 upsample) and 1x1, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
 //
 // These layers are 1-8 GFLOP each: neither MFMA nor HBM bound, but bound by what ONE CU can take in (measured 50-70 GB/s
 // per CU from L2, MI355X_MICROARCH.md "Indexed rows") and by exposed round trips.  The kernel therefore (a) moves the
@@ -28,7 +28,7 @@
 #define GG_BOX_WAIT_BARRIER(VM) do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(VM)); __builtin_amdgcn_s_barrier(); } while (0)
 #define GG_BOX_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(63)); __builtin_amdgcn_s_barrier(); } while (0)
 
-template <int TWI, int MT, int CT, int UP>
+template <int TWI, int MT, int CT, int UP, int K3>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
                                                          const int nch_stage, const int gn_bytes, const int q_major)
 {
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     constexpr int RPT = 16 / TWI;
     constexpr int TH = MT * RPT;                      // output rows of the workgroup
     constexpr int NTRIP = CT == 2 ? 2 : 3;            // weight trips (4 k-steps each) kept in flight per wave
-    constexpr int HH = UP ? TH / 2 + 2 : TH + 2;
-    constexpr int HW = UP ? TW / 2 + 2 : TW + 2;
+    constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
+    constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
+    constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
     constexpr int NROWS = HH * HW;
     constexpr int NRB = (NROWS + 15) / 16;            // 1 KiB DMA blocks (16 rows) per chunk plane
     constexpr int PLANE = NRB * 1024;                 // one 32-channel chunk of the box
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     const int n = t / tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
     const int g = CT == 2 ? by : by >> 1, half = CT == 2 ? 0 : by & 1;
-    const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
-    const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
+    const int ih0 = UP ? h0 / 2 - 1 : h0 - PADK;
+    const int iw0 = UP ? w0 / 2 - 1 : w0 - PADK;
 
     f32x4 acc[MT][CT];
 #pragma unroll
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bf16_t *wbase = p.weight + ((long long)g * 9 * p.nchunk << 10) + half * 512;
+    const bf16_t *wbase = p.weight + ((long long)g * NTAPS * p.nchunk << 10) + half * 512;
     const int wl0 = fr * 32 + swz64(fr, fq) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
 
     // staging duty of a lane inside a 16-row DMA block: row (lane>>2), LDS slot (lane&3)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     for (int st = 0; st < nstage; ++st) {
         const int cbase = st * nch_stage;
         const int nch = (p.nchunk - cbase < nch_stage) ? p.nchunk - cbase : nch_stage;
-        const int S = 9 * nch;
+        const int S = NTAPS * nch;
         const int s0 = (S * wave) / NW, s1 = (S * (wave + 1)) / NW;
 
         // GroupNorm scale/shift rows of the stage -> LDS, by DMA as well (256 floats per wave instruction)
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (s + u < s1) {
-                    const int kh = ctap / 3, kw = ctap - kh * 3;
+                    const int kh = K3 ? ctap / 3 : 0, kw = K3 ? ctap - kh * 3 : 0;
                     const char *plane = box + cc * PLANE;
                     const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
                     bf16x8 xf[MT];
@@ -263,18 +264,23 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     static const int force_th = [] { const char *e = getenv("GG_BOX2D_TH"); return e ? atoi(e) : 0; }();
     static const int force_ct = [] { const char *e = getenv("GG_BOX2D_CT"); return e ? atoi(e) : 0; }();
     if (!enabled) return false;
-    if (!(p.kd == 1 && p.kh == 3 && p.kw == 3 && p.D == 1 && p.stride == 1 && p.pad == 1)) return false;
+    const bool k3 = p.kh == 3 && p.kw == 3 && p.pad == 1, k1 = p.kh == 1 && p.kw == 1 && p.pad == 0 && !p.upsample;
+    if (!(p.kd == 1 && p.D == 1 && p.stride == 1 && (k3 || k1))) return false;
+    const int halo = k3 ? 2 : 0;
+    // 1x1: only where the grid is under-filled (measured: 8x8 4.2 vs 8.6 us on the tiny-M kernel, but 64x64 12.0 vs 7.8 us on gather5)
+    static const long long k1_max_m = [] { const char *e = getenv("GG_BOX2D_K1_MAXM"); return e ? atoll(e) : 256LL; }();
+    if (k1 && p.M > k1_max_m) return false;
     const int TWI = p.Wo % 16 == 0 ? 16 : p.Wo % 8 == 0 ? 8 : p.Wo % 4 == 0 ? 4 : 0;   // width of a 16-position MFMA tile
     if (!TWI) return false;
     const int RPT = 16 / TWI;
-    const long long wbytes16 = 16LL * 9 * p.nchunk * 32 * 2;        // weight slice of 16 output channels
+    const long long wbytes16 = 16LL * (k3 ? 9 : 1) * p.nchunk * 32 * 2;   // weight slice of 16 output channels
     double best = 0;
     int bMT = 0, bCT = 0;
     for (int MT : {8, 4, 2, 1}) {
         const int TH = MT * RPT;
         if (p.Ho % TH || (p.upsample && (TH & 1)) || (force_th && MT != force_th)) continue;
         if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
-        const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + 2) * (TWI + 2);
+        const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             if (force_ct && CT != force_ct) continue;
@@ -286,7 +292,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     }
     if (!bMT) return false;                                          // filled grids: the halo / wide-tile kernels win
     const int MT = bMT, CT = bCT, TH = MT * RPT;
-    const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + 2) * (TWI + 2);
+    const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
     const long long plane = (long long)((rows + 15) / 16) * 1024;   // whole 16-row DMA blocks
     long long cap = lds_cap / plane;
     if (cap < 1) return false;
@@ -305,34 +311,34 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     return true;
 }
 
-template <int TWI, int MT, int CT, int UP>
+template <int TWI, int MT, int CT, int UP, int K3>
 static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_set = true;
     }
     const int tiles_h = p.Ho / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
-    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
+    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
                        pl.nch_stage, pl.gn_bytes, pl.q_major);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
 
-template <int CT, int UP>
+template <int CT, int UP, int K3>
 static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     switch (pl.TWI * 10 + pl.MT) {
-        case 168: return launch_box<16, 8, CT, UP>(p, pl, stream);
-        case 164: return launch_box<16, 4, CT, UP>(p, pl, stream);
-        case 162: return launch_box<16, 2, CT, UP>(p, pl, stream);
-        case 84: return launch_box<8, 4, CT, UP>(p, pl, stream);
-        case 82: return launch_box<8, 2, CT, UP>(p, pl, stream);
-        case 81: return launch_box<8, 1, CT, UP>(p, pl, stream);
-        case 41: return launch_box<4, 1, CT, UP>(p, pl, stream);
+        case 168: return launch_box<16, 8, CT, UP, K3>(p, pl, stream);
+        case 164: return launch_box<16, 4, CT, UP, K3>(p, pl, stream);
+        case 162: return launch_box<16, 2, CT, UP, K3>(p, pl, stream);
+        case 84: return launch_box<8, 4, CT, UP, K3>(p, pl, stream);
+        case 82: return launch_box<8, 2, CT, UP, K3>(p, pl, stream);
+        case 81: return launch_box<8, 1, CT, UP, K3>(p, pl, stream);
+        case 41: return launch_box<4, 1, CT, UP, K3>(p, pl, stream);
         default: return GG_ERR_UNSUPPORTED;
     }
 }
@@ -354,6 +360,7 @@ int gg_conv_box_try(const ConvParams &p, hipStream_t stream)
     BoxPlan pl;
     if (!plan_box(p, pl)) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
-    if (pl.CT == 2) return p.upsample ? dispatch_box<2, 1>(p, pl, stream) : dispatch_box<2, 0>(p, pl, stream);
-    return p.upsample ? dispatch_box<1, 1>(p, pl, stream) : dispatch_box<1, 0>(p, pl, stream);
+    if (p.kh == 1) return pl.CT == 2 ? dispatch_box<2, 0, 0>(p, pl, stream) : dispatch_box<1, 0, 0>(p, pl, stream);
+    if (pl.CT == 2) return p.upsample ? dispatch_box<2, 1, 1>(p, pl, stream) : dispatch_box<2, 0, 1>(p, pl, stream);
+    return p.upsample ? dispatch_box<1, 1, 1>(p, pl, stream) : dispatch_box<1, 0, 1>(p, pl, stream);
 }

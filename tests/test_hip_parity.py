@@ -253,6 +253,24 @@ def test_conv_box_kernel_matches_oracle(dev, case):
         assert float(out.t[..., Cout:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", [(1, 640, 1920, (8, 8)), (2, 160, 480, (16, 32)), (1, 800, 800, (4, 4)), (1, 320, 160, (24, 16))],
+                         ids=["qkv_8x8", "qkv_16x32_n2", "proj_4x4", "skip_24x16"])
+def test_conv_box_kernel_1x1_with_residual(dev, cfg):
+    """1x1 convs (attention qkv / proj, ResBlock skip) on the box kernel: the box is the tile itself, one tap."""
+    from jointimagegeneration_amd import ops
+    N, Cin, Cout, sp = cfg
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn((N, Cin) + sp, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn((N, Cout) + sp, generator=g)
+    ref = O.conv(bf(x), bf(w), b) + bf(res)
+    xcl = ops.to_cl(x.to(dev))
+    out = ops.conv(xcl, ops.pack_conv_weight(w.to(dev), xcl.Cpad), ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1, 1, 1), pad=0,
+                   residual=ops.to_cl(res.to(dev)))
+    assert rel_err(ops.from_cl(out, 2), ref) < 1e-2
+
+
 def test_conv_box_two_source_prologue_residual_two_stages(dev):
     """Box kernel with everything fused: concat of two sources, GroupNorm(*SiLU) prologue, per-sample bias, residual; 1280 input
     channels do not fit one LDS stage, so the box is staged twice."""
