@@ -67,6 +67,12 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     const int ih0 = UP ? h0 / 2 - 1 : h0 - PADK;
     const int iw0 = UP ? w0 / 2 - 1 : w0 - PADK;
 
+    // final pass: thread -> f32x4 slot (tid & 63) of slices (tid >> 6) + 8k; with CT | 8 its 4 couts are the same for every k,
+    // so the bias is fetched here, a whole kernel ahead of its use
+    const int co_thr = g * 32 + half * 16 + ((tid >> 6) % CT) * 16 + (lane >> 4) * 4;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co_thr);
+
     f32x4 acc[MT][CT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -223,16 +229,14 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
     GG_BOX_LDS_BARRIER();
-    const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
     for (int i = tid; i < MT * CT * 64; i += 512) {
         f32x4 a = red[i];
 #pragma unroll
         for (int w = 1; w < NW; ++w) a += red[w * MT * CT * 64 + i];
-        const int l = i & 63, ct = (i >> 6) % CT, tt = (i >> 6) / CT;
-        const int co = g * 32 + half * 16 + ct * 16 + (l >> 4) * 4;
-        if (brow) a += *reinterpret_cast<const f32x4 *>(brow + co);
+        const int l = i & 63, tt = (i >> 6) / CT;
+        a += bias4;
         const long long mo = ((long long)n * p.Ho + (h0 + tt * RPT + (l & 15) / TWI)) * p.Wo + (w0 + (l & 15) % TWI);
-        const long long o = mo * p.Cout_pad + co;
+        const long long o = mo * p.Cout_pad + co_thr;
         if (p.residual) {
             const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
 #pragma unroll
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (co + j >= p.Cout) a[j] = 0.f;
+            if (co_thr + j >= p.Cout) a[j] = 0.f;
         if (p.out_dtype == GG_F32) {
             *reinterpret_cast<f32x4 *>((float *)p.out + o) = a;
         } else {
