@@ -61,20 +61,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     const bf16_t *kbase = p.k + (long long)n * p.Tkv * p.ldk + (long long)h * p.hsk;
     const bf16_t *vbase = p.v + (long long)n * p.Tkv * p.ldv + (long long)h * p.hsv;
 
+    // K/V tiles go global -> registers -> LDS; the registers of tile t+1 are requested before tile t is consumed, so the
+    // load round trip (1.5-2 us) hides behind the MFMA/softmax work instead of adding to every tile
+    constexpr int NP = (KT * CH + 255) / 256;          // 16-byte pieces per thread and operand
+    constexpr bool PREFETCH = NP <= 4;                 // 32 VGPRs at most (D <= 256)
+    u32x4 kreg[NP], vreg[NP];
+    auto fetch = [&](int key0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / CH, c = i - r * CH;
+            kreg[j] = u32x4{0u, 0u, 0u, 0u};
+            vreg[j] = u32x4{0u, 0u, 0u, 0u};
+            if (i < KT * CH && key0 + r < p.Tkv) {
+                kreg[j] = *reinterpret_cast<const u32x4 *>(kbase + (long long)(key0 + r) * p.ldk + c * 8);
+                vreg[j] = *reinterpret_cast<const u32x4 *>(vbase + (long long)(key0 + r) * p.ldv + c * 8);
+            }
+        }
+    };
+    if (PREFETCH) fetch(0);
     for (int key0 = 0; key0 < p.Tkv; key0 += KT) {
         __syncthreads();   // previous tile fully consumed
-        for (int i = tid; i < KT * CH; i += 256) {
-            int r = i / CH, c = i - r * CH;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key0 + r < p.Tkv) {
-                kv = *reinterpret_cast<const u32x4 *>(kbase + (long long)(key0 + r) * p.ldk + c * 8);
-                vv = *reinterpret_cast<const u32x4 *>(vbase + (long long)(key0 + r) * p.ldv + c * 8);
+        if (!PREFETCH) fetch(key0);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / CH, c = i - r * CH;
+            if (i < KT * CH) {
+                const int off = r * ROWB + swz_row<CH>(r, c) * 16;
+                *reinterpret_cast<u32x4 *>(ksm + off) = kreg[j];
+                *reinterpret_cast<u32x4 *>(vsm + off) = vreg[j];
             }
-            int off = r * ROWB + swz_row<CH>(r, c) * 16;
-            *reinterpret_cast<u32x4 *>(ksm + off) = kv;
-            *reinterpret_cast<u32x4 *>(vsm + off) = vv;
         }
         __syncthreads();
+        if (PREFETCH && key0 + KT < p.Tkv) fetch(key0 + KT);
 
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
