@@ -270,7 +270,9 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (!NT) NT = 1;
     const long long blocks = tiles * (G / NT);
     static const long long min_blocks = [] { const char *e = getenv("GG_HALO_MIN_BLOCKS"); return e ? atoll(e) : 128LL; }();
-    if (blocks < min_blocks) return GG_ERR_UNSUPPORTED;    // under-filled grid: split-K gather path is faster
+    // 2-D: under one workgroup per CU the box-resident kernel wins (AE 512->512 @64x64: 136 us here at 128 workgroups)
+    static const long long min_blocks_2d = [] { const char *e = getenv("GG_HALO_MIN_BLOCKS_2D"); return e ? atoll(e) : 256LL; }();
+    if (blocks < (d3 ? min_blocks : min_blocks_2d)) return GG_ERR_UNSUPPORTED;    // under-filled grid: box / split-K gather paths are faster
     if (stream == (hipStream_t)-1) return GG_OK;
     if (d3) return p.upsample ? dispatch_nt<1, 1>(p, NT, stream) : dispatch_nt<1, 0>(p, NT, stream);
     return p.upsample ? dispatch_nt<0, 1>(p, NT, stream) : dispatch_nt<0, 0>(p, NT, stream);

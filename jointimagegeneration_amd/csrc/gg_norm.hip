@@ -76,11 +76,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     __shared__ double ra[256], rb[256];
     double a = 0.0, b = 0.0;
     const int total = nblk * cpg;
-    for (int i = tid; i < total; i += 256) {
-        const int k = i / cpg, j = i - k * cpg;
-        const float *q = part + (((long long)n * nblk + k) * C + g * cpg + j) * 2;
-        a += (double)q[0];
-        b += (double)q[1];
+    // 4 independent 8-byte loads in flight per thread (the fold of 1024 partial blocks is otherwise 16+ serial round trips)
+    for (int i0 = tid; i0 < total; i0 += 1024) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = float2{0.f, 0.f};
+            if (i < total) {
+                const int k = i / cpg, j = i - k * cpg;
+                v[u] = *reinterpret_cast<const float2 *>(part + (((long long)n * nblk + k) * C + g * cpg + j) * 2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += (double)v[u].x; b += (double)v[u].y; }
     }
     ra[tid] = a;
     rb[tid] = b;
