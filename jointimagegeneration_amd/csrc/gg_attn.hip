@@ -96,68 +96,82 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
         __syncthreads();
         if (PREFETCH && key0 + KT < p.Tkv) fetch(key0 + KT);
 
+        // One online-softmax step covers G x 32 keys (up to 128): the max / sum lane reductions and the rescale of O happen once
+        // per step, and the G S^T tiles, 8G exponentials and G PV products inside a step are independent, so a single wave per
+        // SIMD (under-filled grids: T <= 1024 at batch 1) is not serialised on 4 shuffle round trips per 32 keys.
+        // (Splitting the keys of a 16-query workgroup over its 4 waves instead was slower: 4x the K/V staging per query.)
+        constexpr int G = KT / 32 >= 4 ? 4 : KT / 32;
 #pragma unroll
-        for (int sub = 0; sub < KT / 32; ++sub) {
-            if (key0 + sub * 32 >= p.Tkv) break;
-            // ---- S^T for 32 keys: two 16-key tiles
-            f32x4 s[2];
+        for (int sub0 = 0; sub0 < KT / 32; sub0 += G) {
+            if (key0 + sub0 * 32 >= p.Tkv) break;
+            // ---- S^T for G x 32 keys: 2G 16-key tiles
+            f32x4 s[G][2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int r = sub * 32 + kt * 16 + fr;
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ksm + r * ROWB + swz_row<CH>(r, ks * 4 + g) * 16);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                for (int kt = 0; kt < 2; ++kt) {
+                    s[gi][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int r = (sub0 + gi) * 32 + kt * 16 + fr;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        bf16x8 kf = *reinterpret_cast<const bf16x8 *>(ksm + r * ROWB + swz_row<CH>(r, ks * 4 + g) * 16);
+                        s[gi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[gi][kt], 0, 0, 0);
+                    }
                 }
-            }
             // ---- online softmax (fp32, base-2)
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int key = key0 + sub * 32 + kt * 16 + 4 * g + r;
-                    float v = (key < p.Tkv) ? s[kt][r] * p.scale_log2 : -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + (sub0 + gi) * 32 + kt * 16 + 4 * g + r;
+                        const float v = (key < p.Tkv) ? s[gi][kt][r] * p.scale_log2 : -INFINITY;
+                        s[gi][kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = exp2f(m_run - m_new);
             float rs = 0.f;
-            bf16x8 pf;
+            bf16x8 pf[G];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = exp2f(s[kt][r] - m_new);
-                    rs += pv;
-                    pf[kt * 4 + r] = (bf16_t)pv;
-                }
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = exp2f(s[gi][kt][r] - m_new);
+                        rs += pv;
+                        pf[gi][kt * 4 + r] = (bf16_t)pv;
+                    }
             rs += __shfl_xor(rs, 16);
             rs += __shfl_xor(rs, 32);
             l_run = l_run * alpha + rs;
             m_run = m_new;
-            // ---- O^T += V^T P^T
+            // ---- O^T = alpha * O^T + V^T P^T
             const int qrow = fr >> 2, pcol = fr & 3;
-            const int vr0 = sub * 32 + 4 * g + qrow, vr1 = vr0 + 16;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int chunk = 2 * dt + (pcol >> 1);
                 const int sub8 = (pcol & 1) * 8;
-                s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4 *)(vsm + vr0 * ROWB + swz_row<CH>(vr0, chunk) * 16 + sub8));
-                s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4 *)(vsm + vr1 * ROWB + swz_row<CH>(vr1, chunk) * 16 + sub8));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
                 f32x4 acc = o[dt];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc, 0, 0, 0);
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    const int vr0 = (sub0 + gi) * 32 + 4 * g + qrow, vr1 = vr0 + 16;
+                    s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(vsm + vr0 * ROWB + swz_row<CH>(vr0, chunk) * 16 + sub8));
+                    s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(vsm + vr1 * ROWB + swz_row<CH>(vr1, chunk) * 16 + sub8));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf[gi], acc, 0, 0, 0);
+                }
+                o[dt] = acc;
             }
         }
     }
@@ -199,7 +213,7 @@ extern "C" int gg_attention_forward(const gg_attention_desc *d, void *stream_)
     p.scale_log2 = d->scale * 1.4426950408889634f;
     p.q = (const bf16_t *)d->q; p.k = (const bf16_t *)d->k; p.v = (const bf16_t *)d->v; p.out = (bf16_t *)d->out;
     switch (d->head_dim) {
-        case 32: return launch_attn<32, 128>(p, stream);
+        case 32: return launch_attn<32, 256>(p, stream);
         case 64: return launch_attn<64, 64>(p, stream);
         case 128: return launch_attn<128, 64>(p, stream);
         case 256: return launch_attn<256, 32>(p, stream);
