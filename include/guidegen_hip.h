@@ -79,6 +79,11 @@ typedef struct {
     int32_t *tile_counters;    /* optional, >= 65536 int32, ZERO on entry and left zero on exit, used by one stream at a time:
                                   enables the in-launch split-K combine (last-arriving K slice reduces + runs the epilogue);
                                   NULL = separate deterministic reduce launch. Results are bit-identical either way. */
+    int64_t *gn_acc;           /* optional [N][4][Cout_pad][2] int64 (4 stripes by position tile, summed by the consumer), caller-zeroed: the epilogue adds, per output channel, the sum
+                                  and the sum of squares of the bf16-rounded outputs in fixed point (2^28 / 2^20 fractional
+                                  bits; integer atomics commute, so the result is bit-reproducible).  It is the GroupNorm
+                                  statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc.  Only filled when
+                                  gg_conv_emits_stats(desc) == 1 (box / 160-step kernels without split-K, bf16 output). */
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -93,6 +98,8 @@ int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
 /* 1 if this shape runs on the halo-tile kernel, where the GroupNorm prologue is applied once per staged element (callers
  * then skip the separate gg_groupnorm_apply pass); 0 if it runs on the generic gather kernel. Pointers are not read. */
 int gg_conv_fuses_prologue(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) will fill desc->gn_acc (see there); pointers are not read. */
+int gg_conv_emits_stats(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -110,6 +117,12 @@ int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2, int32_t C
 /* y = act(x*scale[n,c] + shift[n,c]) ; act: 0 none, 1 SiLU.  out: bf16 CL [N,S,C1+C2]. */
 int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
                        const float *scale, const float *shift, int32_t act, void *out, void *stream);
+/* The same normalise*affine(+SiLU), with the statistics taken from the per-channel fixed-point accumulators that the producing
+ * convs left behind (gg_conv_desc.gn_acc): acc1 [N][4][C1][2], acc2 [N][4][C2][2] (NULL iff C2 == 0).  Every block folds the
+ * accumulators into the per-channel scale/shift table in LDS (fp64), so no statistics launch is needed. */
+int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2, const int64_t *acc2,
+                           int32_t N, int64_t S, int32_t C_logical, const float *gamma, const float *beta, float eps,
+                           int32_t act, void *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention: out = softmax(scale * Q K^T) V, flash-style (no TxT buffer), MFMA 16x16x32 bf16, fp32 softmax.

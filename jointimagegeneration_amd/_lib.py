@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("kd", i32), ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
         ("Do", i32), ("Ho", i32), ("Wo", i32), ("out_dtype", i32), ("prologue_act", i32), ("reserved", i32),
         ("src1", vp), ("src2", vp), ("weight", vp), ("bias", vp), ("bias_stride", i64),
-        ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("tile_counters", vp),
+        ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("tile_counters", vp), ("gn_acc", vp),
     ]
 
 
@@ -45,9 +45,11 @@ SIGNATURES = {
     "gg_conv_forward": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "gg_conv_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
     "gg_conv_fuses_prologue": (C.c_int, [C.POINTER(ConvDesc)]),
+    "gg_conv_emits_stats": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_groupnorm_workspace_bytes": (i64, [i32, i64, i32]),
     "gg_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i64, vp]),
     "gg_groupnorm_apply": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, vp, i32, vp, vp]),
+    "gg_groupnorm_apply_acc": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i64, i32, vp, vp, f32, i32, vp, vp]),
     "gg_attention_forward": (C.c_int, [C.POINTER(AttentionDesc), vp]),
     "gg_layernorm": (C.c_int, [vp, i64, i32, vp, vp, f32, vp, vp]),
     "gg_geglu": (C.c_int, [vp, i64, i32, vp, vp]),

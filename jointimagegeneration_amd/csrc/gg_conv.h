@@ -15,7 +15,14 @@ struct ConvParams {
     float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
     int *counters;            // per output tile arrival tickets (zero on entry, zero on exit) or nullptr
     int splitk;
+    long long *gn_acc;        // per-channel fixed-point (sum, sumsq) accumulators of the outputs [N][Cout_pad][2], or nullptr
 };
+
+// fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample
+#define GG_ACC_SUM_SCALE 268435456.0f   /* 2^28 */
+#define GG_ACC_SQ_SCALE 1048576.0f      /* 2^20 */
+// accumulators are striped [N][GG_ACC_STRIPES][C][2] by position tile, so that at most P/4 workgroups add to one address
+#define GG_ACC_STRIPES 4
 
 // 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = r0 + (l&15), chunk = l>>4).
 // chunk ^ ((row>>1)&2) puts the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) on 16
@@ -23,3 +30,14 @@ struct ConvParams {
 // the shifted reads of the conv taps (row offsets +1, +18, +180) stay conflict-free, not only the aligned ones.
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 1) & 2); }
 
+
+// Sum over the 16 lanes of a row (lanes with equal l >> 4) with DPP moves only: quad xor 1, quad xor 2, half-row mirror, row
+// mirror.  Every lane of the row ends up with the row total (fixed order: deterministic).  4 VALU ops instead of 4 ds_bpermute.
+__device__ __forceinline__ float gg_row16_sum(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+    return x;
+}

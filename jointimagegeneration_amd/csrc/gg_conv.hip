@@ -459,12 +459,17 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
     }
 
     const long long m = m0 + wave * 16 + fr;
-    if (m >= p.M) return;
+    const bool mvalid = m < p.M;
+    const bool stats = p.gn_acc && p.splitk == 1 && p.out_dtype != GG_F32;     // GroupNorm statistics of the NEXT norm
+    float sv[2][4], sq[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int co = g0 * 32 + ct * 16 + fq * 4;
         f32x4 v = acc[ct];
         const long long o = m * p.Cout_pad + co;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sv[ct][j] = sq[ct][j] = 0.f;
+        if (!mvalid) continue;
         if (p.splitk > 1) {
             *reinterpret_cast<f32x4 *>(p.ws + (long long)blockIdx.z * p.M * p.Cout_pad + o) = v;
             continue;
@@ -483,8 +488,32 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
         } else {
             bf16x4 ob;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+            for (int j = 0; j < 4; ++j) {
+                ob[j] = (bf16_t)v[j];
+                const float f = (float)ob[j];           // statistics of what the next norm will read
+                sv[ct][j] = f;
+                sq[ct][j] = f * f;
+            }
             *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+        }
+    }
+    if (stats) {   // host guarantees Do*Ho*Wo % 64 == 0: the 64 rows of the block belong to one sample
+        __shared__ float statp[4][32][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = gg_row16_sum(sv[ct][j]), b = gg_row16_sum(sq[ct][j]);   // over the wave's 16 rows
+                if (fr == 0) { statp[wave][ct * 16 + fq * 4 + j][0] = a; statp[wave][ct * 16 + fq * 4 + j][1] = b; }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid >> 1, which = tid & 1;
+            const float t = ((statp[0][c][which] + statp[1][c][which]) + statp[2][c][which]) + statp[3][c][which];
+            const long long fx = __double2ll_rn((double)t * (double)(which ? GG_ACC_SQ_SCALE : GG_ACC_SUM_SCALE));
+            const long long nb = (long long)((unsigned)m0 / osp);
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.gn_acc + (((nb * GG_ACC_STRIPES + (blockIdx.x & (GG_ACC_STRIPES - 1))) * p.Cout_pad + g0 * 32 + c) * 2 + which)),
+                      (unsigned long long)fx);
         }
     }
 }
@@ -665,7 +694,10 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.ws = nullptr;
     p.counters = nullptr;
     p.splitk = 1;
+    p.gn_acc = (long long *)d->gn_acc;
 }
+
+static bool halo_try_dry(const ConvParams &p) { return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK; }
 
 extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 {
@@ -678,6 +710,21 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
     if (!g5_fuse || gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, 1)) return 0;
     const long long osp = (long long)d->Do * d->Ho * d->Wo;
     return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) && osp % 64 == 0 && d->C1 + d->C2 <= 2560) ? 1 : 0;
+}
+
+bool gg_conv_box_emits_stats(const ConvParams &p);
+
+// Which path a desc takes is decided by the same plan functions gg_conv_forward uses.
+extern "C" int gg_conv_emits_stats(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->out_dtype != GG_BF16) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    if (halo_try_dry(p)) return 0;
+    if (gg_conv_box_try(p, (hipStream_t)-1) == GG_OK) return gg_conv_box_emits_stats(p) ? 1 : 0;
+    if (gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, p.prologue_act)) return 0;
+    const long long osp = (long long)d->Do * d->Ho * d->Wo;
+    return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) == 1 && osp % 64 == 0) ? 1 : 0;
 }
 
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     if ((gridDim.x & 7) == 0) v = (v & 7) * (gridDim.x >> 3) + (v >> 3);
     const int by = q_major ? v / P : v % Q;
     int t = q_major ? v - by * P : v / Q;
+    const int stripe = t & (GG_ACC_STRIPES - 1);       // GroupNorm accumulator stripe of this position tile
     const int tw = t % tiles_w; t /= tiles_w;
     const int th = t % tiles_h;
     const int n = t / tiles_h;
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
     GG_BOX_LDS_BARRIER();
+    const bool stats = p.gn_acc && p.out_dtype != GG_F32;       // GroupNorm statistics of the NEXT norm (see gg_conv_desc.gn_acc)
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < MT * CT * 64; i += 512) {
         f32x4 a = red[i];
 #pragma unroll
@@ -250,8 +253,35 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         } else {
             bf16x4 ob;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)a[j];
+            for (int j = 0; j < 4; ++j) {
+                ob[j] = (bf16_t)a[j];
+                const float f = (float)ob[j];               // what the next norm will read
+                ssum[j] += f;
+                ssq[j] += f * f;
+            }
             *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+        }
+    }
+    if (stats) {
+        // a thread's slices (tid>>6) + 8k share their 4 couts; its lane's position (l & 15) is reduced over the 16 lanes of the row
+        // by DPP moves, the 8 waves through LDS in a fixed order, then ONE wave instruction of 64-bit integer atomics per block
+        __shared__ float statp[8][16][2];                    // [wave][cq * 4 + j][sum | sumsq]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = gg_row16_sum(ssum[j]), b = gg_row16_sum(ssq[j]);
+            if ((lane & 15) == 0) { statp[wave][(lane >> 4) * 4 + j][0] = a; statp[wave][(lane >> 4) * 4 + j][1] = b; }
+        }
+        __syncthreads();
+        if (tid < 32 * CT) {
+            const int which = tid & 1, c = tid >> 1;         // channel c of the block's 16*CT couts
+            const int ct = c >> 4, cw = c & 15;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (w % CT == ct) t += statp[w][cw][which];  // waves whose slices carry cout tile ct, fixed order
+            const long long fx = __double2ll_rn((double)t * (double)(which ? GG_ACC_SQ_SCALE : GG_ACC_SUM_SCALE));
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.gn_acc + ((((long long)n * GG_ACC_STRIPES + stripe) * p.Cout_pad + g * 32 + half * 16 + c) * 2 + which)),
+                      (unsigned long long)fx);
         }
     }
 }
@@ -320,7 +350,7 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
 {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_set = true;
     }
@@ -357,6 +387,8 @@ bool gg_conv_box_fuses_prologue(const ConvParams &p)
     if (!plan_box(p, pl)) return false;
     return p.Cout_pad / (16 * pl.CT) <= fuse_q;
 }
+
+bool gg_conv_box_emits_stats(const ConvParams &p) { return p.out_dtype != GG_F32; }
 
 // Returns GG_ERR_UNSUPPORTED (silently) when the shape is outside the envelope.  stream == (hipStream_t)-1: dry run.
 int gg_conv_box_try(const ConvParams &p, hipStream_t stream)

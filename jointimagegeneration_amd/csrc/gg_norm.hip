@@ -264,6 +264,148 @@ extern "C" int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// normalise*affine(+SiLU) with the statistics read from the per-channel fixed-point accumulators left behind by the
+// producing convs (gg_conv_desc.gn_acc): no statistics launch at all.  Every block folds (sum, sumsq) of its sample's
+// channels into the scale/shift table in LDS (fp64 per group), then applies its share of the rows.  All global reads
+// (accumulators, gamma/beta, the thread's first pieces) are issued up front: one memory round trip per block.
+#define GG_ACC_SUM_SCALE_D 268435456.0   /* 2^28, must match gg_conv.h */
+#define GG_ACC_SQ_SCALE_D 1048576.0      /* 2^20 */
+__global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restrict__ s1, int C1, const long long *__restrict__ acc1,
+                                                           const bf16_t *__restrict__ s2, int C2, const long long *__restrict__ acc2,
+                                                           long long S, int C_logical, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps, int act, bf16_t *__restrict__ out)
+{
+    const int C = C1 + C2;
+    const int P = C >> 3;
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int cpg = C_logical / 32;
+    extern __shared__ double chs[];                    // [C] sum, [C] sumsq; then reused: float scale[C], shift[C]
+    __shared__ float gmean[32], grstd[32];
+    const long long pieces = S * P;
+    const bf16_t *b1 = s1 + (long long)n * S * C1;
+    const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
+    bf16_t *o = out + (long long)n * S * C;
+    constexpr int U = 2, CPT = 8;                      // pieces prefetched per thread; channels per thread (C <= 2048)
+    const long long stride = (long long)gridDim.x * 256;
+    const long long i0 = (long long)blockIdx.x * 256 + tid;
+    u32x4 pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long i = i0 + u * stride;
+        pv[u] = u32x4{0u, 0u, 0u, 0u};
+        if (i < pieces) {
+            const long long row = i / P;
+            const int c0 = (int)(i - row * P) * 8;
+            pv[u] = *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0);
+        }
+    }
+    float gam[CPT], bet[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        gam[k] = 0.f;
+        bet[k] = 0.f;
+        long long a = 0, b = 0;
+        if (c < C) {
+            // 4 stripes per sample (GG_ACC_STRIPES in gg_conv.h): integer sums, exact in any order
+            const long long *q = (c < C1) ? acc1 + ((long long)n * 4 * C1 + c) * 2 : acc2 + ((long long)n * 4 * C2 + (c - C1)) * 2;
+            const long long cs = (c < C1) ? (long long)C1 * 2 : (long long)C2 * 2;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                a += q[st * cs];
+                b += q[st * cs + 1];
+            }
+            if (c < C_logical) { gam[k] = gamma[c]; bet[k] = beta[c]; }
+            chs[c] = (double)a * (1.0 / GG_ACC_SUM_SCALE_D);
+            chs[C + c] = (double)b * (1.0 / GG_ACC_SQ_SCALE_D);
+        }
+    }
+    __syncthreads();
+    {   // group fold by all 256 threads: 8 lanes per group, fixed-order xor tree (fp64 adds only; no fp64 division / sqrt)
+        const int g = tid >> 3, sub = tid & 7;
+        double a = 0.0, b = 0.0;
+        for (int c = g * cpg + sub; c < (g + 1) * cpg; c += 8) { a += chs[c]; b += chs[C + c]; }
+#pragma unroll
+        for (int x = 1; x < 8; x <<= 1) {
+            a += __shfl_xor(a, x);
+            b += __shfl_xor(b, x);
+        }
+        if (sub == 0) {
+            const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 for every shape here
+            const double mean = a * inv;
+            double var = b * inv - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gmean[g] = (float)mean;
+            grstd[g] = rsqrtf((float)var + eps);
+        }
+    }
+    __syncthreads();
+    float *ss = reinterpret_cast<float *>(chs);        // the double sums are dead
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+            float sc = 0.f, sh = 0.f;
+            if (c < C_logical) {
+                const int g = c / cpg;
+                sc = grstd[g] * gam[k];
+                sh = bet[k] - gmean[g] * sc;
+            }
+            ss[c] = sc;
+            ss[C + c] = sh;
+        }
+    }
+    __syncthreads();
+    auto emit = [&](long long i, const u32x4 raw) {
+        const long long row = i / P;
+        const int c0 = (int)(i - row * P) * 8;
+        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ss + c0), a1 = *reinterpret_cast<const f32x4 *>(ss + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(ss + C + c0), h1 = *reinterpret_cast<const f32x4 *>(ss + C + c0 + 4);
+        bf16x8 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y0 = (float)v[j] * a0[j] + h0[j];
+            float y1 = (float)v[j + 4] * a1[j] + h1[j];
+            if (act) { y0 = gg_silu(y0); y1 = gg_silu(y1); }
+            y[j] = (bf16_t)y0;
+            y[j + 4] = (bf16_t)y1;
+        }
+        *reinterpret_cast<bf16x8 *>(o + row * C + c0) = y;
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (i0 + u * stride < pieces) emit(i0 + u * stride, pv[u]);
+    for (long long i = i0 + U * stride; i < pieces; i += stride) {
+        const long long row = i / P;
+        const int c0 = (int)(i - row * P) * 8;
+        emit(i, *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0));
+    }
+}
+
+extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2,
+                                      const int64_t *acc2, int32_t N, int64_t S, int32_t C_logical, const float *gamma,
+                                      const float *beta, float eps, int32_t act, void *out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int C = C1 + C2;
+    if (C1 <= 0 || C1 % 32 || C2 % 32 || C2 < 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_apply_acc: C1/C2 must be multiples of 32");
+    if (C_logical % 32 || C_logical > C || C_logical <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_apply_acc: logical channels %d not divisible by 32 groups", C_logical);
+    if (C > 2048) GG_FAIL(GG_ERR_UNSUPPORTED, "groupnorm_apply_acc: C > 2048");
+    if (!src1 || !acc1 || (C2 && (!src2 || !acc2)) || !gamma || !beta || !out || N <= 0 || S <= 0)
+        GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_apply_acc: null pointer / empty");
+    const long long pieces = (long long)S * (C / 8);
+    long long blocks = (pieces + 511) / 512;   // ~2 pieces per thread: the table fold is paid once per block
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gn_apply_acc_kernel, dim3((unsigned)blocks, N), dim3(256), C * 2 * sizeof(double), stream, (const bf16_t *)src1, C1,
+                       (const long long *)acc1, (const bf16_t *)src2, C2, (const long long *)acc2, (long long)S, C_logical, gamma, beta, eps,
+                       act, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, fp32 two-pass (row cached in registers: C <= 64*8*4 = 2048)
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t *__restrict__ x, long long rows, int C,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,

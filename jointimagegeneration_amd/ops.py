@@ -6,6 +6,8 @@ with zero pad lanes, plus the logical channel count.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -54,6 +56,7 @@ class CL:
     """Channels-last activation: t is [N, D, H, W, Cpad] (bf16, or fp32 for head outputs); C = logical channels."""
     t: torch.Tensor
     C: int
+    acc: Optional[torch.Tensor] = None      # int64 [N, 4, Cpad, 2]: striped fixed-point per-channel (sum, sumsq) left by the producing conv
 
     @property
     def N(self): return self.t.shape[0]
@@ -150,6 +153,46 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
     return bool(lib.gg_conv_fuses_prologue(C.byref(d)))
 
 
+# ---- GroupNorm statistics emitted by conv epilogues (gg_conv_desc.gn_acc).  One int64 arena per device, bump-allocated per
+# network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
+GN_ACC = os.environ.get("GG_GN_ACC", "1") != "0"
+GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
+_ARENA_ENTRIES = 1 << 20            # 8 MiB of int64
+_ARENAS = {}
+
+
+def stats_begin(device) -> None:
+    """Start of a network forward: zero what the previous forward used and rewind."""
+    if not GN_ACC:
+        return
+    a = _ARENAS.get(str(device))
+    if a is None:
+        _ARENAS[str(device)] = dict(buf=torch.zeros(_ARENA_ENTRIES, dtype=torch.int64, device=device), off=0, used=0, active=True)
+        return
+    a["used"] = max(a["used"], a["off"])
+    if a["used"]:
+        a["buf"][:a["used"]].zero_()
+    a["off"] = 0
+    a["active"] = True
+
+
+def stats_end(device) -> None:
+    a = _ARENAS.get(str(device))
+    if a is not None:
+        a["used"] = max(a["used"], a["off"])
+        a["active"] = False
+
+
+def _stats_alloc(device, N: int, cp: int) -> Optional[torch.Tensor]:
+    a = _ARENAS.get(str(device))
+    n = N * 4 * cp * 2                  # 4 stripes (GG_ACC_STRIPES)
+    if a is None or not a["active"] or a["off"] + n > _ARENA_ENTRIES:
+        return None
+    v = a["buf"][a["off"]:a["off"] + n].view(N, 4, cp, 2)
+    a["off"] += n
+    return v
+
+
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
@@ -185,8 +228,13 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
         if IN_LAUNCH_SPLITK_COMBINE:
             d.tile_counters = _tile_counters(t1.device).data_ptr()
+    acc = None
+    if GN_ACC and d.out_dtype == GG_BF16 and Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS and lib.gg_conv_emits_stats(C.byref(d)):
+        acc = _stats_alloc(t1.device, N, cp)
+        if acc is not None:
+            d.gn_acc = acc.data_ptr()
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
-    return CL(out, cout)
+    return CL(out, cout, acc)
 
 
 # ----------------------------------------------------------------------------------------------- norms / elementwise
@@ -219,6 +267,26 @@ def groupnorm_apply(src1: CL, scale: torch.Tensor, shift: torch.Tensor, act: boo
     check(lib.gg_groupnorm_apply(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, scale.data_ptr(),
                                  shift.data_ptr(), 1 if act else 0, out.data_ptr(), _stream()), "gg_groupnorm_apply")
     return CL(out, src1.C + (src2.C if src2 is not None else 0))
+
+
+def groupnorm_apply_acc(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool, src2: Optional[CL] = None) -> CL:
+    """act(GroupNorm(32)(cat[src1, src2])) with the statistics taken from the accumulators the producing convs left in CL.acc."""
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    if src2 is not None and src1.C != C1:
+        raise RuntimeError("two-source GroupNorm needs an unpadded first source")
+    out = torch.empty(tuple(src1.t.shape[:4]) + (C1 + C2,), dtype=torch.bfloat16, device=src1.t.device)
+    check(lib.gg_groupnorm_apply_acc(src1.t.data_ptr(), C1, src1.acc.data_ptr(), _ptr(src2.t) if src2 is not None else None, C2,
+                                     src2.acc.data_ptr() if src2 is not None else None, N, S, c_log, gamma.data_ptr(),
+                                     beta.data_ptr(), eps, 1 if act else 0, out.data_ptr(), _stream()), "gg_groupnorm_apply_acc")
+    return CL(out, c_log)
+
+
+def has_stats(src1: CL, src2: Optional[CL] = None) -> bool:
+    return GN_ACC and src1.acc is not None and (src2 is None or src2.acc is not None) and src1.Cpad + (src2.Cpad if src2 is not None else 0) <= 2048
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

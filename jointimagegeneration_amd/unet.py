@@ -116,17 +116,21 @@ class _UNetBase(nn.Module):
             off, cp = lay[id(rb)]
             return bias_row[off:off + N * cp]
 
-        hs = []
-        h = x
-        for module in self.input_blocks:
-            h = module.run(h, tb, context)
-            hs.append(h)
-        h = self.middle_block.run(h, tb, context)
-        for module in self.output_blocks:
-            h = module.run(h, tb, context, skip=hs.pop())
-        conv = self.out[2]
-        pw, pb = packed_conv(conv, h.Cpad)
-        return norm_conv(h, self.out[0], True, pw, pb, conv.weight.shape[0], k=_k3(conv.weight), out_f32=True, out=head_out)
+        ops.stats_begin(x.t.device)        # conv epilogues of this forward leave GroupNorm sums in the (zeroed) arena
+        try:
+            hs = []
+            h = x
+            for module in self.input_blocks:
+                h = module.run(h, tb, context)
+                hs.append(h)
+            h = self.middle_block.run(h, tb, context)
+            for module in self.output_blocks:
+                h = module.run(h, tb, context, skip=hs.pop())
+            conv = self.out[2]
+            pw, pb = packed_conv(conv, h.Cpad)
+            return norm_conv(h, self.out[0], True, pw, pb, conv.weight.shape[0], k=_k3(conv.weight), out_f32=True, out=head_out)
+        finally:
+            ops.stats_end(x.t.device)
 
 
 class CCDMUNetModel(_UNetBase):

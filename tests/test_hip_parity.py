@@ -325,6 +325,53 @@ def test_groupnorm_silu(dev, shape):
         assert rel_err(got, ref) < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [(1, 160, 160, (16, 16), 3), (2, 320, 640, (8, 8), 3), (1, 160, 320, (32, 32), 1), (1, 640, 640, (8, 8), 1),
+                                 (1, 800, 800, (4, 4), 3)], ids=["box3x3_16", "box3x3_8_n2", "gather5_1x1_32", "box1x1_8", "box3x3_4"])
+def test_conv_epilogue_groupnorm_statistics(dev, cfg):
+    """Convs of the latent UNet leave per-channel fixed-point (sum, sumsq) of their bf16 outputs behind (gg_conv_desc.gn_acc);
+    gg_groupnorm_apply_acc normalises from them.  Checked against the stored tensor's own statistics, against the oracle's
+    GroupNorm, and for bit-reproducibility (integer atomics commute)."""
+    from jointimagegeneration_amd import ops
+    N, Cin, Cout, sp, k = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn((N, Cin) + sp, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn((N, Cout) + sp, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    xcl = ops.to_cl(x.to(dev))
+    pw, pb = ops.pack_conv_weight(w.to(dev), xcl.Cpad), ops.pad_bias(b.to(dev), Cout, dev)
+    outs = []
+    for _ in range(2):
+        ops.stats_begin(dev)
+        y = ops.conv(xcl, pw, pb, Cout, k=(1, k, k), pad=k // 2, residual=ops.to_cl(res.to(dev)))
+        ops.stats_end(dev)
+        assert y.acc is not None, "this shape is expected to emit statistics"
+        outs.append((y, y.acc.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])                             # bit-reproducible
+    y, acc = outs[1]
+    yt = y.t.float().reshape(N, -1, y.Cpad)                                # [N, S, C]
+    s_ref, q_ref = yt.sum(1).double(), (yt * yt).sum(1).double()
+    s_got, q_got = acc.sum(1)[..., 0].double() / 2 ** 28, acc.sum(1)[..., 1].double() / 2 ** 20
+    S = yt.shape[1]
+    assert float((s_got - s_ref).abs().max()) < 1e-3 * S ** 0.5 + 1e-3
+    assert float(((q_got - q_ref).abs() / (q_ref.abs() + 1.0)).max()) < 1e-3
+    ref = O.silu(O.group_norm(ops.from_cl(y, 2).cpu(), gamma, beta, 1e-5))
+    got = ops.groupnorm_apply_acc(ops.CL(y.t, y.C, acc), gamma.to(dev), beta.to(dev), 1e-5, True)
+    assert rel_err(ops.from_cl(got, 2), ref) < 1e-2
+    sc, sh = ops.groupnorm_stats(y, gamma.to(dev), beta.to(dev), 1e-5)
+    old = ops.groupnorm_apply(y, sc, sh, True)
+    assert float((got.t.float() - old.t.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # two sources (skip concat): statistics of both tensors, groups straddling the boundary
+    if cfg[0] == 1 and Cout == 160:
+        y2 = outs[0][0]
+        gamma2, beta2 = 1 + 0.1 * torch.randn(320, generator=g), 0.1 * torch.randn(320, generator=g)
+        cat = torch.cat([ops.from_cl(y, 2).cpu(), ops.from_cl(y2, 2).cpu()], 1)
+        ref2 = O.group_norm(cat, gamma2, beta2, 1e-6)
+        got2 = ops.groupnorm_apply_acc(ops.CL(y.t, y.C, acc), gamma2.to(dev), beta2.to(dev), 1e-6, False, src2=ops.CL(y2.t, y2.C, outs[0][1]))
+        assert rel_err(ops.from_cl(got2, 2), ref2) < 1e-2
+
+
 def test_layernorm_geglu_add_linear_embedding(dev):
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -19,6 +19,7 @@ if os.environ.get("PROBE_PRO"):      # GroupNorm*SiLU in front of the conv: fuse
         f = lambda: ops.conv(x, pw, pb, Cout, k=(1, k, k), pad=k // 2, prologue=(sc, sh))
     else:
         f = lambda: ops.conv(ops.groupnorm_apply(x, sc, sh, True), pw, pb, Cout, k=(1, k, k), pad=k // 2)
+if os.environ.get("PROBE_ACC"): ops.stats_begin(dev)      # convs emit GroupNorm sums into the arena
 f(); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
