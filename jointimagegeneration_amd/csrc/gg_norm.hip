@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     const int P = C >> 3;
     const int tid = threadIdx.x, n = blockIdx.y;
     const int cpg = C_logical / 32;
-    extern __shared__ double chs[];                    // [C] sum, [C] sumsq; then reused: float scale[C], shift[C]
+    extern __shared__ float ss[];                      // scale[C], shift[C]
+    __shared__ unsigned long long gacc[32][2];         // per-group integer (sum, sumsq): LDS atomics, exact in any order
     __shared__ float gmean[32], grstd[32];
     const long long pieces = S * P;
     const bf16_t *b1 = s1 + (long long)n * S * C1;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     constexpr int U = 2, CPT = 8;                      // pieces prefetched per thread; channels per thread (C <= 2048)
     const long long stride = (long long)gridDim.x * 256;
     const long long i0 = (long long)blockIdx.x * 256 + tid;
+    if (tid < 64) gacc[tid >> 1][tid & 1] = 0ull;
     u32x4 pv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -299,48 +301,52 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
             pv[u] = *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0);
         }
     }
+    // this thread's channels: 4 stripes x (sum, sumsq) as 16-byte loads, gamma / beta; everything requested before the first wait
     float gam[CPT], bet[CPT];
+    long long sa[CPT], sb[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
         gam[k] = 0.f;
         bet[k] = 0.f;
-        long long a = 0, b = 0;
-        if (c < C) {
-            // 4 stripes per sample (GG_ACC_STRIPES in gg_conv.h): integer sums, exact in any order
+        sa[k] = 0;
+        sb[k] = 0;
+        if (c < C_logical) {
             const long long *q = (c < C1) ? acc1 + ((long long)n * 4 * C1 + c) * 2 : acc2 + ((long long)n * 4 * C2 + (c - C1)) * 2;
             const long long cs = (c < C1) ? (long long)C1 * 2 : (long long)C2 * 2;
+            typedef __attribute__((ext_vector_type(2))) long long i64x2;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                a += q[st * cs];
-                b += q[st * cs + 1];
+                const i64x2 v = *reinterpret_cast<const i64x2 *>(q + st * cs);
+                sa[k] += v[0];
+                sb[k] += v[1];
             }
-            if (c < C_logical) { gam[k] = gamma[c]; bet[k] = beta[c]; }
-            chs[c] = (double)a * (1.0 / GG_ACC_SUM_SCALE_D);
-            chs[C + c] = (double)b * (1.0 / GG_ACC_SQ_SCALE_D);
+            gam[k] = gamma[c];
+            bet[k] = beta[c];
         }
     }
-    __syncthreads();
-    {   // group fold by all 256 threads: 8 lanes per group, fixed-order xor tree (fp64 adds only; no fp64 division / sqrt)
-        const int g = tid >> 3, sub = tid & 7;
-        double a = 0.0, b = 0.0;
-        for (int c = g * cpg + sub; c < (g + 1) * cpg; c += 8) { a += chs[c]; b += chs[C + c]; }
+    __syncthreads();                                   // gacc zeroed
 #pragma unroll
-        for (int x = 1; x < 8; x <<= 1) {
-            a += __shfl_xor(a, x);
-            b += __shfl_xor(b, x);
-        }
-        if (sub == 0) {
-            const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 for every shape here
-            const double mean = a * inv;
-            double var = b * inv - mean * mean;
-            if (var < 0.0) var = 0.0;
-            gmean[g] = (float)mean;
-            grstd[g] = rsqrtf((float)var + eps);
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C_logical) {
+            const int g = c / cpg;
+            atomicAdd(&gacc[g][0], (unsigned long long)sa[k]);
+            atomicAdd(&gacc[g][1], (unsigned long long)sb[k]);
         }
     }
     __syncthreads();
-    float *ss = reinterpret_cast<float *>(chs);        // the double sums are dead
+    if (tid < 32) {
+        const double a = (double)(long long)gacc[tid][0] * (1.0 / GG_ACC_SUM_SCALE_D);
+        const double b = (double)(long long)gacc[tid][1] * (1.0 / GG_ACC_SQ_SCALE_D);
+        const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 for every shape here
+        const double mean = a * inv;
+        double var = b * inv - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmean[tid] = (float)mean;
+        grstd[tid] = rsqrtf((float)var + eps);
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
@@ -398,7 +404,7 @@ extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_
     long long blocks = (pieces + 511) / 512;   // ~2 pieces per thread: the table fold is paid once per block
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(gn_apply_acc_kernel, dim3((unsigned)blocks, N), dim3(256), C * 2 * sizeof(double), stream, (const bf16_t *)src1, C1,
+    hipLaunchKernelGGL(gn_apply_acc_kernel, dim3((unsigned)blocks, N), dim3(256), C * 2 * sizeof(float), stream, (const bf16_t *)src1, C1,
                        (const long long *)acc1, (const bf16_t *)src2, C2, (const long long *)acc2, (long long)S, C_logical, gamma, beta, eps,
                        act, (bf16_t *)out);
     GG_CHECK_LAUNCH();

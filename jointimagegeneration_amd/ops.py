@@ -157,6 +157,7 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 # network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
 GN_ACC = os.environ.get("GG_GN_ACC", "1") != "0"
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
+GN_ACC_MIN_ELEMS = int(os.environ.get("GG_GN_ACC_MIN", str(1 << 18)))   # below this the one-launch statistics kernel is as fast (5 us)
 _ARENA_ENTRIES = 1 << 20            # 8 MiB of int64
 _ARENAS = {}
 
@@ -229,7 +230,8 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         if IN_LAUNCH_SPLITK_COMBINE:
             d.tile_counters = _tile_counters(t1.device).data_ptr()
     acc = None
-    if GN_ACC and d.out_dtype == GG_BF16 and Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS and lib.gg_conv_emits_stats(C.byref(d)):
+    if (GN_ACC and d.out_dtype == GG_BF16 and GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS
+            and lib.gg_conv_emits_stats(C.byref(d))):
         acc = _stats_alloc(t1.device, N, cp)
         if acc is not None:
             d.gn_acc = acc.data_ptr()
