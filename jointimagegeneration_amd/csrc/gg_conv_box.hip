@@ -238,7 +238,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         for (int w = 1; w < NW; ++w) a += red[w * MT * CT * 64 + i];
         const int l = i & 63, tt = (i >> 6) / CT;
         a += bias4;
-        const long long mo = ((long long)n * p.Ho + (h0 + tt * RPT + (l & 15) / TWI)) * p.Wo + (w0 + (l & 15) % TWI);
+        const int oh = h0 + tt * RPT + (l & 15) / TWI;
+        if (oh >= p.Ho) continue;                           // ragged last row tile (Ho not a multiple of the tile height)
+        const long long mo = ((long long)n * p.Ho + oh) * p.Wo + (w0 + (l & 15) % TWI);
         const long long o = mo * p.Cout_pad + co_thr;
         if (p.residual) {
             const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
@@ -310,17 +312,24 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     const long long wbytes16 = 16LL * (k3 ? 9 : 1) * p.nchunk * 32 * 2;   // weight slice of 16 output channels
     double best = 0;
     int bMT = 0, bCT = 0;
-    for (int MT : {8, 4, 2, 1}) {
+    // tile heights: powers of two, plus 12 / 6 / 3 rows for 16-wide tiles so that 240 (not 160 or 320) workgroups cover the
+    // 64 / 32 / 16-row levels; the last row tile may be ragged (rows >= Ho are computed on zero padding and not stored)
+    for (int MT : {12, 8, 6, 4, 3, 2, 1}) {
         const int TH = MT * RPT;
-        if (p.Ho % TH || (p.upsample && (TH & 1)) || (force_th && MT != force_th)) continue;
+        if ((p.upsample && (TH & 1)) || TH > p.Ho || (force_th && MT != force_th)) continue;
+        if (TWI != 16 && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
         if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
         const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             if (force_ct && CT != force_ct) continue;
-            const long long blocks = (long long)p.N * (p.Ho / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
-            if (blocks > max_blocks) continue;
-            const double cost = (double)(wbytes16 * CT + boxb) * (double)((blocks + 255) / 256);
+            const long long blocks = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
+            if (blocks > max_blocks || 8LL * MT * CT * 1024 > lds_cap) continue;      // grid cap; the 8-wave combine area must fit
+            // every extra LDS stage is another exposed staging round trip
+            const long long plane_c = (long long)((rows + 15) / 16) * 1024;
+            const long long cap_c = lds_cap / plane_c > 0 ? lds_cap / plane_c : 1;
+            const long long nst = (p.nchunk + cap_c - 1) / cap_c;
+            const double cost = (double)(wbytes16 * CT + boxb) * (double)((blocks + 255) / 256) * (1.0 + 0.15 * (double)(nst - 1));
             if (!bMT || cost < best * 0.97) { best = cost; bMT = MT; bCT = CT; }
         }
     }
@@ -338,7 +347,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     if (smem < red) smem = red;
     const int gn_bytes = p.prologue_act ? (nch_stage * 32 * 8 + 1023) / 1024 * 1024 : 0;
     // XCD locality: a run of workgroups shares weights (cout-major) when the weights are the bigger re-fetch, else boxes
-    const long long P = (long long)p.N * (p.Ho / TH) * (p.Wo / TWI), Q = p.Cout_pad / (16 * CT);
+    const long long P = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI), Q = p.Cout_pad / (16 * CT);
     const long long wtot = wbytes16 * (p.Cout_pad / 16), xtot = (long long)p.N * p.H * p.W * p.nchunk * 64;
     const long long cost_q = wtot + xtot * (Q < 8 ? Q : 8), cost_p = wtot * (P < 8 ? P : 8) + xtot;
     pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes};
@@ -354,7 +363,7 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
             return GG_ERR_UNSUPPORTED;
         attr_set = true;
     }
-    const int tiles_h = p.Ho / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
+    const int tiles_h = (p.Ho + MT * (16 / TWI) - 1) / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
     hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
                        pl.nch_stage, pl.gn_bytes, pl.q_major);
@@ -366,7 +375,10 @@ template <int CT, int UP, int K3>
 static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     switch (pl.TWI * 10 + pl.MT) {
+        case 172: return launch_box<16, 12, CT, UP, K3>(p, pl, stream);
         case 168: return launch_box<16, 8, CT, UP, K3>(p, pl, stream);
+        case 166: return launch_box<16, 6, CT, UP, K3>(p, pl, stream);
+        case 163: return launch_box<16, 3, CT, UP, K3>(p, pl, stream);
         case 164: return launch_box<16, 4, CT, UP, K3>(p, pl, stream);
         case 162: return launch_box<16, 2, CT, UP, K3>(p, pl, stream);
         case 84: return launch_box<8, 4, CT, UP, K3>(p, pl, stream);

@@ -231,6 +231,11 @@ BOX_CASES = [
     ("box_w4_n3", 3, 64, 32, (4, 4), False),
     ("box_w8_up", 2, 160, 160, (4, 4), True),
     ("box_w8_three_stages", 1, 1280, 64, (8, 8), False),
+    # ragged row tiles (12 / 6 / 3 rows): 240 workgroups on the 64 / 32 / 16-row levels, last tile partly outside the image
+    ("box_ragged12", 1, 160, 160, (64, 64), False),
+    ("box_ragged6", 1, 64, 320, (32, 32), False),
+    ("box_ragged3", 1, 96, 640, (16, 16), False),
+    ("box_ragged_up", 1, 64, 320, (16, 16), True),
 ]
 
 
