@@ -12,6 +12,9 @@ w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) / (Cin * 27) ** 0.5
 pw = ops.pack_conv_weight(w, Cin)
 pb = ops.pad_bias(None, Cout, dev)
 f = lambda: ops.conv(x, pw, pb, Cout, k=(3, 3, 3))
+if os.environ.get("PROBE_PRO"):      # with the fused GroupNorm*SiLU prologue (the way the CCDM ResBlocks call it)
+    sc, sh = ops.groupnorm_stats(x, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), 1e-5)
+    f = lambda: ops.conv(x, pw, pb, Cout, k=(3, 3, 3), prologue=(sc, sh))
 f(); torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(reps): f()
