@@ -35,10 +35,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     constexpr int ROWB = D * 2;
     constexpr int KS = D / 32;         // k-steps of the S^T product
     constexpr int DT = D / 16;         // d tiles of O^T
-    __shared__ __attribute__((aligned(16))) char smem[2 * KT * ROWB];
+    // D >= 256 (AE mid-block attention: one head of 384 / 512 channels): a K/V tile is 48-64 KiB and the register staging path
+    // cannot prefetch it; there the tiles are double-buffered in LDS and filled by LDS-DMA one tile ahead (one wave instruction
+    // per K or V row), hand-counted vmcnt.  (Inline-asm DMA: the compiler would drain all LDS-DMA before every ds_read.)
+    constexpr bool DMA = D >= 256;
+    constexpr int TILEB = 2 * KT * ROWB;               // K tile + V tile
+    __shared__ __attribute__((aligned(1024))) char smem[(DMA ? 2 : 1) * TILEB];
     char *ksm = smem, *vsm = smem + KT * ROWB;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (LDS-DMA destinations live in M0)
     const int fr = lane & 15, g = lane >> 4;
     const int n = blockIdx.z, h = blockIdx.y;
     const int q0 = blockIdx.x * 64 + wave * 16;
@@ -79,8 +85,38 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
             }
         }
     };
-    if (PREFETCH) fetch(0);
-    for (int key0 = 0; key0 < p.Tkv; key0 += KT) {
+    const unsigned smem_off = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
+    auto stage_dma = [&](int key0, int buf) {          // this wave's rows r = wave, wave + 4, ...: 2 * KT / 4 DMA instructions
+#pragma unroll
+        for (int rr = 0; rr < KT / 4; ++rr) {
+            const int r = rr * 4 + wave;
+            int key = key0 + r;
+            if (key >= p.Tkv) key = p.Tkv - 1;         // rows past the end are masked (-inf scores), any finite data will do
+            const int c = lane ^ (r & 15);             // LDS chunk slot `lane` of row r holds global chunk c (swz_row is an involution)
+            if (lane < CH) {
+                const bf16_t *ks = kbase + (long long)key * p.ldk + c * 8;
+                const bf16_t *vs = vbase + (long long)key * p.ldv + c * 8;
+                const unsigned kd = __builtin_amdgcn_readfirstlane(smem_off + buf * TILEB + r * ROWB), vd = kd + KT * ROWB;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ks), "s"(kd) : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vs), "s"(vd) : "memory", "m0");
+            }
+        }
+    };
+    if (DMA) stage_dma(0, 0);
+    if (!DMA && PREFETCH) fetch(0);
+    int tile = 0;
+    for (int key0 = 0; key0 < p.Tkv; key0 += KT, ++tile) {
+        if (DMA) {
+            const bool more = key0 + KT < p.Tkv;
+            if (more) stage_dma(key0 + KT, (tile + 1) & 1);          // the other buffer: last read one tile ago, barrier since
+            // this wave's 2*KT/4 DMAs of the current tile have landed once at most the next tile's are outstanding
+            if (more) __builtin_amdgcn_s_waitcnt(((2 * KT / 4) & 15) | (((2 * KT / 4) >> 4) << 14) | 0x0F70);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            ksm = smem + (tile & 1) * TILEB;
+            vsm = ksm + KT * ROWB;
+        } else {
         __syncthreads();   // previous tile fully consumed
         if (!PREFETCH) fetch(key0);
 #pragma unroll
@@ -95,6 +131,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
         }
         __syncthreads();
         if (PREFETCH && key0 + KT < p.Tkv) fetch(key0 + KT);
+        }
 
         // One online-softmax step covers G x 32 keys (up to 128): the max / sum lane reductions and the rescale of O happen once
         // per step, and the G S^T tiles, 8G exponentials and G PV products inside a step are independent, so a single wave per
@@ -173,6 +210,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
                 }
                 o[dt] = acc;
             }
+        }
+        if (DMA) {                                     // every wave is done with this buffer before it is refilled two tiles on
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS reads have returned
+            __builtin_amdgcn_s_barrier();
         }
     }
 
