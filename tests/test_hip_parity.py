@@ -276,6 +276,62 @@ def test_conv_box_kernel_1x1_with_residual(dev, cfg):
     assert rel_err(ops.from_cl(out, 2), ref) < 1e-2
 
 
+def test_conv_box_kernel_randomised_sweep(dev):
+    """Seeded sweep over the box kernel's envelope (tile widths 16/8/4, ragged row tiles, 3x3 / 1x1, upsample, batch, two
+    sources, prologue, residual, per-sample bias, Cout not a multiple of 32) against the oracle."""
+    from jointimagegeneration_amd import ops
+    rng = np.random.RandomState(1234)
+    checked = 0
+    for it in range(28):
+        W = int(rng.choice([4, 8, 16, 32]))
+        H = int(rng.choice([4, 6, 8, 12, 20, 24])) if W >= 8 else 4
+        if H % 32 == 0:
+            H += 4
+        k = int(rng.choice([3, 3, 3, 1]))
+        up = bool(k == 3 and rng.rand() < 0.25)
+        if up and (H % 2 or W < 8):
+            up = False
+        N = int(rng.choice([1, 1, 2, 3]))
+        C1 = int(rng.choice([32, 64, 96, 160]))
+        C2 = int(rng.choice([0, 0, 32, 64])) if not up else 0
+        Cout = int(rng.choice([14, 32, 48, 64, 160, 200]))
+        use_pro = bool(rng.rand() < 0.4) and k == 3
+        use_res = bool(rng.rand() < 0.5)
+        per_sample = bool(rng.rand() < 0.5)
+        hin, win = (H // 2, W // 2) if up else (H, W)
+        g = torch.Generator().manual_seed(1000 + it)
+        x1 = torch.randn(N, C1, hin, win, generator=g)
+        x2 = torch.randn(N, C2, hin, win, generator=g) if C2 else None
+        Cin = C1 + C2
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        tb = torch.randn(N if per_sample else 1, Cout, generator=g) * 0.2
+        res = torch.randn(N, Cout, H, W, generator=g) if use_res else None
+        gamma, beta = 1 + 0.1 * torch.randn(Cin, generator=g), 0.1 * torch.randn(Cin, generator=g)
+        xc = torch.cat([bf(x1), bf(x2)], 1) if C2 else bf(x1)
+        c1 = ops.to_cl(x1.to(dev))
+        c2 = ops.to_cl(x2.to(dev)) if C2 else None
+        if not ops.conv_out_extent or c1.Cpad != C1:
+            continue
+        a = xc
+        pro = None
+        if use_pro:
+            a = bf(O.silu(O.group_norm(xc, gamma, beta, 1e-5)))
+            pro = ops.groupnorm_stats(c1, gamma.to(dev), beta.to(dev), 1e-5, src2=c2)
+        a = O.upsample_nearest2(a) if up else a
+        ref = O.conv(a, bf(w), None, padding=k // 2) + tb[:, :, None, None]
+        if use_res:
+            ref = ref + bf(res)
+        tbp = torch.zeros(tb.shape[0], ops.pad32(Cout), device=dev); tbp[:, :Cout] = tb.to(dev)
+        out = ops.conv(c1, ops.pack_conv_weight(w.to(dev), Cin), tbp if per_sample else tbp[0], Cout, k=(1, k, k), pad=k // 2, upsample=up,
+                       src2=c2, residual=ops.to_cl(res.to(dev)) if use_res else None, bias_per_sample=per_sample, prologue=pro)
+        err = rel_err(ops.from_cl(out, 2), ref)
+        assert err < (1.5e-2 if use_pro else 1e-2), (it, N, C1, C2, Cout, H, W, k, up, use_pro, use_res, per_sample, err)
+        if out.Cpad > Cout:
+            assert float(out.t[..., Cout:].float().abs().max()) == 0.0
+        checked += 1
+    assert checked >= 20
+
+
 def test_conv_box_two_source_prologue_residual_two_stages(dev):
     """Box kernel with everything fused: concat of two sources, GroupNorm(*SiLU) prologue, per-sample bias, residual; 1280 input
     channels do not fit one LDS stage, so the box is staged twice."""
