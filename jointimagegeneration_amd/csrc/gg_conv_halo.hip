@@ -82,7 +82,7 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
     // Box image swizzle: chunk ^ f(hw) with f depending only on the position INSIDE a W-line (hw), found by exhaustive search
     // to keep every ds_read_b128 lane group of the three kw taps on 16 distinct 16-byte slots.  Unlike a row-based map it is
     // invariant under the kd / kh shifts (whole W-lines), so an operand address is ONE add: lane_off[kw] + line * (HW * 64)
-    // (the row-based map cost 5 VALU per read, 40 per tap; measured 587 -> 548 us on 64->64 @128^3).
+    // (the row-based map cost 5 VALU per read, 40 per tap; same-box A/B on 64->64 @128^3: 545-565 vs 568-578 us).
     constexpr unsigned FMASK = UP ? 0x3C0u : 0xFC30u;      // f(hw) = 2 for hw in {6..9} (upsample) / {4,5,10..15}
     auto fsw = [&](int hw) -> int { return (int)((FMASK >> hw) & 1u) << 1; };
     int lane_off[3];
