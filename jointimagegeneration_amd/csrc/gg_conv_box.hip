@@ -314,8 +314,10 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     int bMT = 0, bCT = 0;
     // tile heights: powers of two, plus 12 / 6 / 3 rows for 16-wide tiles so that 240 (not 160 or 320) workgroups cover the
     // 64 / 32 / 16-row levels; the last row tile may be ragged (rows >= Ho are computed on zero padding and not stored)
+    static const int ragged_on = [] { const char *e = getenv("GG_BOX2D_RAGGED"); return e ? atoi(e) : 1; }();
     for (int MT : {12, 8, 6, 4, 3, 2, 1}) {
         const int TH = MT * RPT;
+        if (!ragged_on && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
         if ((p.upsample && (TH & 1)) || TH > p.Ho || (force_th && MT != force_th)) continue;
         if (TWI != 16 && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
         if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
