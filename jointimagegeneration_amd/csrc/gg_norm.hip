@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     const bf16_t *b1 = s1 + (long long)n * S * C1;
     const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
     float a = 0.f, b = 0.f;
+    // gamma / beta of this thread's channel are requested up front: one memory round trip for the whole kernel, not two
+    float gmm = 0.f, bta = 0.f;
+    if (tid < cpg) { gmm = gamma[g * cpg + tid]; bta = beta[g * cpg + tid]; }
     // 16-byte loads: the group's channels [c_lo, c_hi) live in pieces p_lo..p_hi of a row; lanes mask the foreign channels
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     const int p_lo = c_lo >> 3, p_hi = (c_hi - 1) >> 3;
@@ -146,24 +149,27 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
             b += f * f;
         }
     }
-    __shared__ double ra[256], rb[256];
-    ra[tid] = (double)a;
-    rb[tid] = (double)b;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { ra[tid] += ra[tid + s]; rb[tid] += rb[tid + s]; }
-        __syncthreads();
+    // fixed-order reduction: fp64 butterfly inside each wave (6 steps), then the 4 waves through LDS: one barrier, not eight
+    double da = (double)a, db = (double)b;
+#pragma unroll
+    for (int x = 1; x < 64; x <<= 1) {
+        da += __shfl_xor(da, x);
+        db += __shfl_xor(db, x);
     }
+    __shared__ double ra[4], rb[4];
+    if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
+    __syncthreads();
+    const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
     const double cnt = (double)total;
-    const double mean = ra[0] / cnt;
-    double var = rb[0] / cnt - mean * mean;
+    const double mean = sa / cnt;
+    double var = sb / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
     if (tid < cpg) {
         const int c = g * cpg + tid;
-        const float sc = frstd * gamma[c];
+        const float sc = frstd * gmm;
         scale[(long long)n * C + c] = sc;
-        shift[(long long)n * C + c] = beta[c] - fmean * sc;
+        shift[(long long)n * C + c] = bta - fmean * sc;
     }
     if (g == 0)
         for (int c = C_logical + tid; c < C; c += 256) { scale[(long long)n * C + c] = 0.f; shift[(long long)n * C + c] = 0.f; }
