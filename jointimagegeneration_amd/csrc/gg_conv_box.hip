@@ -224,6 +224,18 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 
     // ---- combine the 8 waves (fixed order), then bias / residual / store.  red[wave][tt][ct][lane] is lane-contiguous:
     //      conflict-free 1 KiB wave writes and reads.
+    // the thread's residual values of the final pass are requested now, a barrier and the 8-wave combine ahead of their use
+    constexpr int EPI = (MT * CT * 64 + 511) / 512;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 resv[EPI];
+#pragma unroll
+    for (int kk = 0; kk < EPI; ++kk) {
+        const int i = tid + 512 * kk;
+        resv[kk] = u32x2{0u, 0u};
+        const int oh = h0 + ((i >> 6) / CT) * RPT + (i & 15) / TWI;
+        if (p.residual && i < MT * CT * 64 && oh < p.Ho)
+            resv[kk] = *reinterpret_cast<const u32x2 *>(p.residual + (((long long)n * p.Ho + oh) * p.Wo + (w0 + (i & 15) % TWI)) * p.Cout_pad + co_thr);
+    }
     f32x4 *red = reinterpret_cast<f32x4 *>(box);
 #pragma unroll
     for (int tt = 0; tt < MT; ++tt)
@@ -232,7 +244,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     GG_BOX_LDS_BARRIER();
     const bool stats = p.gn_acc && p.out_dtype != GG_F32;       // GroupNorm statistics of the NEXT norm (see gg_conv_desc.gn_acc)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < MT * CT * 64; i += 512) {
+#pragma unroll
+    for (int kk = 0; kk < EPI; ++kk) {
+        const int i = tid + 512 * kk;
+        if (i >= MT * CT * 64) break;
         f32x4 a = red[i];
 #pragma unroll
         for (int w = 1; w < NW; ++w) a += red[w * MT * CT * 64 + i];
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         const long long mo = ((long long)n * p.Ho + oh) * p.Wo + (w0 + (l & 15) % TWI);
         const long long o = mo * p.Cout_pad + co_thr;
         if (p.residual) {
-            const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+            const bf16x4 r = __builtin_bit_cast(bf16x4, resv[kk]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] += (float)r[j];
         }
