@@ -387,7 +387,8 @@ def test_groupnorm_silu(dev, shape):
 
 
 @pytest.mark.parametrize("cfg", [(1, 160, 160, (16, 16), 3), (2, 320, 640, (8, 8), 3), (1, 160, 320, (32, 32), 1), (1, 640, 640, (8, 8), 1),
-                                 (1, 800, 800, (4, 4), 3)], ids=["box3x3_16", "box3x3_8_n2", "gather5_1x1_32", "box1x1_8", "box3x3_4"])
+                                 (1, 800, 800, (4, 4), 3), (1, 160, 160, (44, 32), 3), (1, 64, 320, (20, 16), 3)],
+                         ids=["box3x3_16", "box3x3_8_n2", "gather5_1x1_32", "box1x1_8", "box3x3_4", "box_44x32_ragged", "box_20x16_ragged"])
 def test_conv_epilogue_groupnorm_statistics(dev, cfg, monkeypatch):
     """Convs of the latent UNet leave per-channel fixed-point (sum, sumsq) of their bf16 outputs behind (gg_conv_desc.gn_acc);
     gg_groupnorm_apply_acc normalises from them.  Checked against the stored tensor's own statistics, against the oracle's
