@@ -1,53 +1,103 @@
 #!/usr/bin/env python3
 """GuideGen sampling benchmark on MI355X (contract in the task statement; metric from BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
 A "step" is one complete GuideGen volume per GPU (config C5 of BASELINE.json, one independent volume per rank):
   CCDM 3-D categorical UNet, 128^3 mask, 14 classes, 250 reverse steps  ->  stage glue  ->
   LDM autoregressive CT, 256 slices of 512x512: per slice cond-stage encode + 50 DDIM steps (latent 4x64x64) + AE decode.
-value = sampled voxels/s = (N * K * 69 206 016 voxels) / wall time of the K steps (max over ranks), synthetic inputs and
-random-init weights of the reference architectures (no checkpoints or data exist offline), inputs resident in HBM.
+value = sampled voxels/s = (N * steps * 69 206 016 voxels) / wall time of the timed volumes (max over ranks), synthetic inputs
+and random-init weights of the reference architectures (no checkpoints or data exist offline), inputs resident in HBM.
 Volumes are independent => weak scaling, no collective on the data path.
+
+Wall-clock budget.  One volume takes ~20-30 s, so `--steps 20 --warmup 5` would not fit the driver's 600 s limit.  --steps and
+--warmup are therefore UPPER BOUNDS under a budget (`--budget-s`, default 420 s counted from process start): the untimed
+warm-up is the short capture run (weight repack + hipGraph capture on the real shapes) plus as many full warm-up volumes as
+requested AND affordable (at most one), and the timed region runs whole volumes - never truncated slices or steps - until
+`--steps` is reached or the next volume would not fit.  The line reports `steps` = volumes actually timed, `steps_requested`,
+`warmup` = full warm-up volumes actually run, `warmup_requested`.
+
+N > 1.  Under a launcher (torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE set) each process is one rank.  Started directly
+(`python bench.py --gpus 4`, WORLD_SIZE unset) the process becomes a PARENT that never touches the GPU: it starts N child
+ranks (one per LOCAL_RANK, MASTER_ADDR=127.0.0.1), forwards rank 0's JSON line and exits non-zero if any child fails.
 """
 from __future__ import annotations
 
-import argparse
-import json
 import os
 import sys
 import time
 
+T_START = float(os.environ.get("GG_BENCH_T0", "0")) or time.time()
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 VOXELS_PER_VOLUME = 128 ** 3 + 512 * 512 * 256          # 69 206 016
 MFMA_PEAK_TFLOPS = 2500.0                                # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-CCDM_UNET_GFLOP_128 = 12720.7
+HBM_PEAK_GBS = 8000.0
+CCDM_UNET_GFLOP_128 = 12720.7                            # SURVEY.md 8d (torch flop counter over the reference modules)
+LDM_UNET_GFLOP = 124.12                                  # N=1 @64x64
+LDM_UNET_WEIGHT_MB = 535.0                               # 267.5 M params in bf16: streamed once per forward
+AE_DECODE_GFLOP = 2513.31
+COND_ENCODE_GFLOP = 634.51
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=4, help="upper bound on timed volumes per GPU (see --budget-s)")
+    ap.add_argument("--warmup", type=int, default=0, help="upper bound on full warm-up volumes (at most one is run)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("GG_BENCH_BUDGET_S", "420")),
+                    help="wall-clock budget of the whole process, counted from its start")
     ap.add_argument("--ccdm-steps", type=int, default=250, help="CCDM reverse steps (250 = params_eval.yml time_steps)")
     ap.add_argument("--slices", type=int, default=256)
     ap.add_argument("--volumes-per-gpu", type=int, default=1, help="independent volumes sampled concurrently per GPU (BASELINE C5 = 1)")
     ap.add_argument("--max-slices", type=int, default=None, help="DEV ONLY: truncate the slice loop (marks the line partial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ parent launcher
+def launch_ranks(args) -> int:
+    """Parent of a direct `--gpus N` run: no torch import, no GPU call.  One child per rank; rank 0's stdout is ours."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GG_BENCH_T0=repr(T_START), GG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL          # ranks > 0 print nothing on stdout; stderr is shared
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:                             # a failed rank would leave the others in a barrier forever
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ roofline legs
 def conv_roofline(pipe, device):
-    """Dominant kernel = the 3-D halo-tile implicit-GEMM conv (`conv_halo_kernel<1,NT,UP>`) of the CCDM UNet
+    """Judged kernel = the 3-D halo-tile implicit-GEMM conv (`conv_halo_kernel<1,NT,UP>`) of the CCDM UNet
     (3x3x3 convs are 99.3 % of the UNet's FLOPs; the halo kernel runs all of them at the 128^3..32^3 levels).
     One eager 128^3 UNet forward with a HIP event pair around EVERY conv launch, recorded on the stream the kernels are
     launched on; achieved = sum(algorithmic FLOPs of the halo launches) / sum(their durations).  The rocprofv3 average of
     the same kernel name (profiles/) must agree with avg_launch_ms.  traffic: PMC passes parsed by tools/pmc_parse.py."""
+    import torch
     from jointimagegeneration_amd import ops
     from jointimagegeneration_amd.ops import CL
     unet = pipe.ccdm.unet
@@ -72,7 +122,10 @@ def conv_roofline(pipe, device):
 
     ops.conv = timed_conv
     try:
+        ef0, ef1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ef0.record()
         unet.forward_cl(x, row)
+        ef1.record()
         torch.cuda.synchronize()
     finally:
         ops.conv = real_conv
@@ -84,12 +137,42 @@ def conv_roofline(pipe, device):
     out = {"bound": "mfma", "kernel": "conv_halo_kernel<3-D> (3x3x3 implicit GEMM, halo tile) in one CCDM UNet forward @128^3",
            "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
            "traffic": None, "launches": len(halo), "avg_launch_ms": round(t / len(halo) * 1e3, 4), "flops_per_launch": round(fl / len(halo)),
-           "all_3x3x3_convs": {"launches": len(k27), "achieved": round(fl27 / t27 / 1e12, 1), "flops_per_forward": fl27}}
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv3d.json")
-    if os.path.exists(pmc):
-        j = json.load(open(pmc))
-        out["traffic"] = j["traffic_bytes_per_launch"]
-        out["traffic_source"] = "profiles/r01_pmc_conv3d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+           "all_3x3x3_convs": {"launches": len(k27), "achieved": round(fl27 / t27 / 1e12, 1), "flops_per_forward": fl27},
+           "eager_forward_ms_with_event_pairs": round(ef0.elapsed_time(ef1), 2)}
+    for name in ("r02_pmc_conv3d.json", "r01_pmc_conv3d.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            j = json.load(open(pmc))
+            out["traffic"] = j["traffic_bytes_per_launch"]
+            out["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+            break
+    return out
+
+
+def stage_rooflines(pipe, ccdm_ms_per_step):
+    """The stages that make up the wall time of a volume, each against ITS roofline t_roof = max(FLOP / MFMA peak, bytes / HBM
+    peak): HIP events around the captured hipGraph replays of one slice (cond-encode, 50 DDIM steps, decode)."""
+    tm = pipe.time_slice_stages()
+    out = {}
+
+    def entry(name, ms, gflop, mbytes, what):
+        t_mfma, t_hbm = gflop / (MFMA_PEAK_TFLOPS * 1e3) * 1e3, mbytes / (HBM_PEAK_GBS * 1e3) * 1e3     # ms
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        e = {"bound": bound, "what": what, "ms": round(ms, 4), "t_roof_ms": round(max(t_mfma, t_hbm), 4),
+             "frac": round(max(t_mfma, t_hbm) / ms, 4), "mfma_frac": round(t_mfma / ms, 4)}
+        if bound == "hbm":
+            e.update(achieved=round(mbytes / ms, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+        else:
+            e.update(achieved=round(gflop / ms, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s")
+        out[name] = e
+
+    entry("ldm_unet_step_n1_64x64", tm["ddim_step_ms"], LDM_UNET_GFLOP, LDM_UNET_WEIGHT_MB,
+          "one captured DDIM step = latent UNet forward (N=1, 8x64x64 in) + fused update; bytes = bf16 weights streamed once")
+    entry("ae_decode_512", tm["decode_ms"], AE_DECODE_GFLOP, 99.0 + 2 * 67.0, "AutoencoderKL.decode 4x64x64 -> 512x512 (captured graph)")
+    entry("cond_encode_512", tm["encode_ms"], COND_ENCODE_GFLOP, 38.0 + 2 * 50.0, "cond-stage AutoencoderKL.encode 2x512x512 -> 8x64x64 (captured graph)")
+    if ccdm_ms_per_step:
+        entry("ccdm_unet_step_128", ccdm_ms_per_step, CCDM_UNET_GFLOP_128, 190.8 + 15000.0,
+              "one captured CCDM reverse step @128^3 (UNet forward + fused posterior/sample), from the timed volumes")
     return out
 
 
@@ -97,6 +180,7 @@ def cpu_baseline():
     """Oracle (CPU fp32 restatement, validated against the reference in the build container) timed on the host cores on a
     bounded sample of the same workload and extrapolated linearly: one CCDM UNet forward at 64^3 (x8 -> 128^3), one LDM
     UNet forward (N=1, 64^2), one AE decode and one cond-stage encode at 512^2."""
+    import torch
     from jointimagegeneration_amd.pipeline import CCDM_PARAMS, LDM_UNET, ae_config
     from jointimagegeneration_amd.config import instantiate_from_config
     from jointimagegeneration_amd.synth import randomize_parameters
@@ -126,68 +210,150 @@ def cpu_baseline():
                        f"1 AE decode {t_dec:.2f}s + 1 cond-encode {t_enc:.2f}s @512^2 (x256); linear extrapolation to one volume = {per_volume:.0f}s")}
 
 
+# ------------------------------------------------------------------------------------------------ rank body
+def agree(flag: bool) -> bool:
+    """All ranks take the same go / stop decision (logical AND); a 1-element host-side reduce, off the data path."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flag
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))                       # parent: spawns the ranks, never touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
-    if os.environ.get("GG_SINGLE_DEVICE") == "1":      # rehearsal of N > 1 ranks on a one-GPU box (all ranks share cuda:0)
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    world = int(world_env or "1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
+
+    import torch
+    dry = os.environ.get("GG_BENCH_DRY") == "1"           # launcher / protocol rehearsal on CPU ranks (tests): no sampling at all
     from jointimagegeneration_amd import distributed as ggd
-    ggd.init("nccl", device)
-    from jointimagegeneration_amd import _lib
-    from jointimagegeneration_amd.pipeline import GuideGenPipeline, build_ccdm, build_ldm
-    _lib.load()
-    torch.set_grad_enabled(False)
 
     def log(msg):
         if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+            print(f"[bench {time.strftime('%H:%M:%S')} +{time.time() - T_START:5.0f}s] {msg}", file=sys.stderr, flush=True)
 
-    log("building models (random-init weights from the seed recipe)")
-    pipe = GuideGenPipeline(build_ccdm(14, args.ccdm_steps, 1024, device), build_ldm(1024, device), ddim_steps=50)
-    if os.environ.get("GG_NO_GRAPH") == "1":          # profiling aid: rocprofv3 --kernel-trace aborts on long hipGraph replays
-        pipe.ccdm.use_graph = False
-        pipe.sampler.use_graph = False
-        pipe.use_graph = False
-    log("models ready; untimed warm-up (weight repack, hipGraph capture)")
+    if dry:
+        device = None
+        ggd.init("gloo")
+        pipe = None
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+        if os.environ.get("GG_SINGLE_DEVICE") == "1":      # rehearsal of N > 1 ranks on a one-GPU box (all ranks share cuda:0)
+            local = 0
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        ggd.init("nccl", device)
+        from jointimagegeneration_amd import _lib
+        from jointimagegeneration_amd.pipeline import GuideGenPipeline, build_ccdm, build_ldm
+        _lib.load()
+        torch.set_grad_enabled(False)
+        log("building models (random-init weights from the seed recipe)")
+        pipe = GuideGenPipeline(build_ccdm(14, args.ccdm_steps, 1024, device), build_ldm(1024, device), ddim_steps=50)
+        if os.environ.get("GG_NO_GRAPH") == "1":          # profiling aid (rocprofv3 --kernel-trace on long hipGraph replays, DESIGN.md 5)
+            pipe.ccdm.use_graph = False
+            pipe.sampler.use_graph = False
+            pipe.use_graph = False
 
     def one_volume(i):
-        return pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=1024 + rank + 1000 * i,
-                               max_slices=args.max_slices)
+        if dry:
+            time.sleep(0.05)
+            return
+        pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=1024 + rank + 1000 * i,
+                        max_slices=args.max_slices)
 
-    # untimed: weight repack + graph capture warm-up on the real shapes (2 short chains), then W full warm-up steps
-    pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=7, ccdm_init_t=10005, max_slices=3)
-    for i in range(args.warmup):
-        one_volume(-1 - i)
+    # ---- untimed: weight repack + hipGraph capture on the real shapes (a short chain and 3 slices)
+    if not dry:
+        log("untimed warm-up (weight repack, hipGraph capture)")
+        pipe.run_volume(N=args.volumes_per_gpu, mask_size=(128, 128, 128), depth=args.slices, hw=512, seed=7, ccdm_init_t=10005, max_slices=3)
 
-    log(f"timed region: {args.steps} volume(s)")
-    elapsed = ggd.timed_region(lambda: [one_volume(i) for i in range(args.steps)], device)
+    # ---- roofline + CPU baseline legs BEFORE the timed region, so that what is left of the budget is known exactly
+    line_extra = {}
+    if rank == 0 and not dry:
+        if not args.no_roofline:
+            log("roofline legs (HIP events)")
+            line_extra["roofline"] = conv_roofline(pipe, device)
+        if not args.no_cpu_baseline:
+            log("CPU baseline leg (oracle on the host cores, bounded sample)")
+            line_extra["cpu_baseline"] = cpu_baseline()
+            torch.set_num_threads(max(1, min(4, len(os.sched_getaffinity(0)))))
+
+    TAIL_S = 12.0                                            # JSON + stage timings + teardown after the timed region
+    est = None                                               # seconds per volume, measured
+    warm_done = 0
+    ggd.barrier(device)
+    if args.warmup > 0:
+        # a full warm-up volume is affordable only if at least two more volumes fit after it (est. from the previous round: 30 s)
+        guess = 0.05 if dry else float(os.environ.get("GG_BENCH_VOLUME_GUESS_S", "30"))
+        if agree(time.time() - T_START + 3 * guess * 1.1 + TAIL_S <= args.budget_s):
+            t0 = time.time()
+            one_volume(-1)
+            if device is not None:
+                torch.cuda.synchronize()
+            est = time.time() - t0
+            warm_done = 1
+
+    log(f"timed region: up to {args.steps} volume(s) within the {args.budget_s:.0f} s budget")
+    done = 0
+    ggd.barrier(device)
+    t_region = time.time()
+    while done < args.steps:
+        one_volume(done)
+        done += 1
+        if device is not None:
+            torch.cuda.synchronize()
+        now = time.time()
+        per = (now - t_region) / done
+        est = per if est is None else max(per, est * 0.5)
+        if done < args.steps and not agree(now - T_START + per * 1.08 + TAIL_S <= args.budget_s):
+            break
+    ggd.barrier(device)
+    elapsed = time.time() - t_region
+    if world > 1:
+        import torch.distributed as dist
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
 
     if rank == 0:
         partial = args.max_slices is not None or args.ccdm_steps != 250 or args.slices != 256
         line = {
             "metric": "sampled voxels/sec @50 DDIM steps, 128^3 mask + 512^2x256 CT",
-            "value": round(world * args.steps * args.volumes_per_gpu * VOXELS_PER_VOLUME / elapsed, 1), "unit": "voxels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 1),
+            "value": round(world * done * args.volumes_per_gpu * VOXELS_PER_VOLUME / elapsed, 1), "unit": "voxels/s",
+            "n_gpus": world, "steps": done, "warmup": warm_done, "ms_per_step": round(elapsed / done * 1e3, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
+            "warmup_note": "untimed capture run (5 CCDM steps + 3 slices on the real shapes) + `warmup` full volumes; --steps/--warmup are upper bounds under budget_s",
             "config": {"workload": "C5 full GuideGen volume per GPU: CCDM 128^3 K=14 250 steps -> LDM 256 slices x (cond-encode + 50 DDIM @4x64x64 + AE decode 512^2)",
                        "volumes_per_gpu_per_step": args.volumes_per_gpu, "ccdm_steps": args.ccdm_steps, "ddim_steps": 50, "slices": args.slices,
                        "parallelism": f"replicas x{world} (one volume per GPU, no collective)", "weights": "random-init (seed recipe)"},
         }
         if partial:
             line["partial"] = True
-        line["stage_seconds"] = {k: round(v, 2) for k, v in pipe.stats.items()}
-        log("measuring roofline / cpu baseline")
-        if not args.no_roofline:
-            line["roofline"] = conv_roofline(pipe, device)
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if dry:
+            line["dry_run"] = True
+            line["value"] = 0.0
+        else:
+            line["stage_seconds"] = {k: round(v, 2) for k, v in pipe.stats.items()}
+            line.update(line_extra)
+            if "roofline" in line and not partial:
+                try:
+                    line["roofline"]["stages"] = stage_rooflines(pipe, pipe.stats["ccdm_s"] / args.ccdm_steps * 1e3)
+                except Exception as e:                                       # never lose the line to an auxiliary leg
+                    line["roofline"]["stages_error"] = repr(e)
+        line["wall_s_total"] = round(time.time() - T_START, 1)
         print(json.dumps(line), flush=True)
     ggd.finalize()
 

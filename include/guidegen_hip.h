@@ -211,10 +211,12 @@ int gg_lincomb4(const float *e0, const float *e1, const float *e2, const float *
  * workspace: >= 2 floats, zero-initialised by the call. */
 int gg_minmax_normalise(const float *src, int64_t n, float *dst, float *workspace2, void *stream);
 
-/* Stage glue: CCDM labels -> LDM conditioning slice on the device: nearest upsample of the
- * label volume [N,Dm,Hm,Wm] to (D,H,W), torch.rot90(k=3) on (H,W), value label/255 in channel 1, previous generated
- * slice `prev` fp32 [N,H,W] (or NULL = zeros) in channel 0, remaining lanes of the bf16 CL row zeroed
- * (latentdiffusion/sample_diffusion.py:199-210). mask_out (optional) receives the fp32 mask slice. */
+/* Stage glue: CCDM labels -> LDM conditioning slice on the device, replacing the host recipe
+ * rot90(scipy.ndimage.zoom(mask, target / shape, order=0), k=3) / 255 (latentdiffusion/sample_diffusion.py:199-200):
+ * order-0 zoom of the label volume [N,Dm,Hm,Wm] to (D,H,W) with scipy's index rule (output o reads input
+ * floor(o * (in-1)/(out-1) + 0.5) in IEEE double, NOT F.interpolate's floor(o*in/out)), torch.rot90(k=3) on (H,W), value
+ * label/255 in channel 1, previous generated slice `prev` fp32 [N,H,W] (or NULL = zeros) in channel 0, remaining lanes of
+ * the bf16 CL row zeroed (sample_diffusion.py:208-210). mask_out (optional) receives the fp32 mask slice. */
 int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t Dm, int32_t Hm, int32_t Wm, int32_t slice, int32_t D,
                           int32_t H, int32_t W, const float *prev, void *cond_cl, int32_t stride, float *mask_out,
                           void *stream);

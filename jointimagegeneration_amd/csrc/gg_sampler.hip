@@ -342,18 +342,30 @@ extern "C" int gg_minmax_normalise(const float *src, int64_t n, float *dst, floa
 //   cond[n,i,j,0] = prev[n,i,j] (previous generated slice, [0,1]) ; cond[n,i,j,1] = rot[i,j]/255 ; other lanes 0
 // (latentdiffusion/sample_diffusion.py:199-210; value convention ldm/data/ruijin_pimage_and_mask.py:127-131)
 // ------------------------------------------------------------------------------------------------------------
+// Index rule of scipy.ndimage.zoom(order=0) with its defaults (mode="constant", grid_mode=False), which is what the reference's
+// stage-glue recipe calls (latentdiffusion/sample_diffusion.py:199-200): output index o reads input index
+//   floor(o * zf + 0.5),  zf = (in - 1) / (out - 1)  in IEEE double  (NI_ZoomShift: cc = o * zoom; start = floor(cc + 0.5)).
+// It differs from F.interpolate(nearest)'s floor(o * in / out) on 16 % of the indices at 128 -> 512.  The product and the sum are
+// rounded separately (no FMA contraction), as the C code of scipy does, so that the index is bit-identical.
+__device__ __forceinline__ int zoom0_index(int o, double zf, int n_in)
+{
+    const int i = (int)floor(__dadd_rn(__dmul_rn((double)o, zf), 0.5));
+    return i < 0 ? 0 : (i > n_in - 1 ? n_in - 1 : i);
+}
+
 __global__ __launch_bounds__(256) void mask_to_cond_slice_kernel(const int *__restrict__ labels, int N, int Dm, int Hm, int Wm,
-                                                                 int slice, int D, int H, int W, const float *__restrict__ prev,
-                                                                 bf16_t *__restrict__ cond, int stride, float *__restrict__ mask_out)
+                                                                 int slice, int D, int H, int W, double zd, double zh, double zw,
+                                                                 const float *__restrict__ prev, bf16_t *__restrict__ cond, int stride,
+                                                                 float *__restrict__ mask_out)
 {
     const long long total = (long long)N * H * W;
-    const int sd = (int)(((long long)slice * Dm) / D);
+    const int sd = zoom0_index(slice, zd, Dm);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         int j = (int)(t % W);
         int i = (int)((t / W) % H);
         int n = (int)(t / ((long long)W * H));
-        int y = H - 1 - j, x = i;                         // rot90(k=3): out[i][j] = up[H-1-j][i]  (H == W)
-        int sy = (int)(((long long)y * Hm) / H), sx = (int)(((long long)x * Wm) / W);
+        int y = H - 1 - j, x = i;                         // rot90(k=3) on (H, W): out[i][j] = up[H-1-j][i]  (H == W)
+        int sy = zoom0_index(y, zh, Hm), sx = zoom0_index(x, zw, Wm);
         int lab = labels[(((long long)n * Dm + sd) * Hm + sy) * Wm + sx];
         float mv = (float)lab / 255.0f;
         float pv = prev ? prev[t] : 0.f;
@@ -366,6 +378,8 @@ __global__ __launch_bounds__(256) void mask_to_cond_slice_kernel(const int *__re
     }
 }
 
+static double zoom0_factor(int n_in, int n_out) { return n_out > 1 ? (double)(n_in - 1) / (double)(n_out - 1) : 1.0; }
+
 extern "C" int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t Dm, int32_t Hm, int32_t Wm, int32_t slice, int32_t D,
                                      int32_t H, int32_t W, const float *prev, void *cond_cl, int32_t stride, float *mask_out,
                                      void *stream_)
@@ -374,11 +388,12 @@ extern "C" int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t D
     if (H != W) GG_FAIL(GG_ERR_UNSUPPORTED, "mask_to_cond_slice: rot90 needs H == W");
     if (stride % 8 || stride < 8) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: stride");
     if (slice < 0 || slice >= D) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: slice %d outside [0,%d)", slice, D);
+    if (N < 1 || Dm < 1 || Hm < 1 || Wm < 1) GG_FAIL(GG_ERR_BAD_SHAPE, "mask_to_cond_slice: empty label volume");
     long long total = (long long)N * H * W;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(mask_to_cond_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, labels, N, Dm, Hm, Wm, slice,
-                       D, H, W, prev, (bf16_t *)cond_cl, stride, mask_out);
+                       D, H, W, zoom0_factor(Dm, D), zoom0_factor(Hm, H), zoom0_factor(Wm, W), prev, (bf16_t *)cond_cl, stride, mask_out);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -227,17 +227,21 @@ class LitEma(nn.Module):
         self.collected_params = []
 
     def copy_to(self, model):
+        """Writes through `p.copy_` (not `p.data.copy_` as ema.py:57-65 does): the in-place op bumps the parameter's version
+        counter, which is what invalidates the engine's repacked-weight cache, time-bias tables and captured hipGraphs."""
         shadow = dict(self.named_buffers())
-        for key, p in model.named_parameters():
-            if p.requires_grad:
-                p.data.copy_(shadow[self.m_name2s_name[key]].data)
+        with torch.no_grad():
+            for key, p in model.named_parameters():
+                if p.requires_grad:
+                    p.copy_(shadow[self.m_name2s_name[key]])
 
     def store(self, parameters):
-        self.collected_params = [p.clone() for p in parameters]
+        self.collected_params = [p.detach().clone() for p in parameters]
 
     def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
+        with torch.no_grad():
+            for c, p in zip(self.collected_params, parameters):
+                p.copy_(c)
 
 
 class DiffusionWrapper(nn.Module):
@@ -524,12 +528,15 @@ class DDIMSampler(object):
         unet = self.model.model.diffusion_model
         sp3 = (1,) * (3 - len(sp)) + tuple(sp)
         S = self.ddim_timesteps.shape[0]
-        key = (N, Cx, sp3, Cc, S, str(dev))
+        key = (N, Cx, sp3, Cc, str(dev))
+        # everything cached below is a function of the schedule (steps, eta -> sigmas) and of the UNet's weights (time-bias
+        # table, packed weights baked into the captured graph): a changed schedule or weight version rebuilds the state
+        token = (S, tuple(float(v) for v in self.ddim_sigmas), ops.weights_token(unet))
         st = self._graphs.get(key)
-        if st is not None:
+        if st is not None and st["token"] == token:
             return st
         steps = torch.tensor(np.flip(self.ddim_timesteps).copy(), dtype=torch.float32, device=dev)
-        st = dict(N=N, Cx=Cx, sp3=sp3, Cc=Cc, S=S,
+        st = dict(N=N, Cx=Cx, sp3=sp3, Cc=Cc, S=S, token=token,
                   table=unet.time_bias_table(steps, N), scal=self.step_scalar_table().to(dev),
                   x=torch.empty((N,) + sp3 + (Cx,), dtype=torch.float32, device=dev),
                   pred_x0=torch.empty((N,) + sp3 + (Cx,), dtype=torch.float32, device=dev),

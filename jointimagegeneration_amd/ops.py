@@ -47,6 +47,17 @@ def _tile_counters(device) -> torch.Tensor:
     return _COUNTERS[key]
 
 
+def weights_token(module) -> Tuple[int, int, int]:
+    """Cheap identity of a module's current weights: (#tensors, sum of in-place version counters, sum of storage addresses).
+    load_state_dict, LitEma.copy_to / restore and optimizer steps write in place (version bump); .to(device) moves storage."""
+    n = v = a = 0
+    for p in module.parameters():
+        n += 1
+        v += p._version
+        a += p.data_ptr()
+    return n, v, a
+
+
 def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
@@ -403,6 +414,14 @@ def mask_to_cond_slice(labels: torch.Tensor, slice_idx: int, D: int, H: int, W: 
     N, Dm, Hm, Wm = labels.shape
     check(lib.gg_mask_to_cond_slice(labels.data_ptr(), N, Dm, Hm, Wm, slice_idx, D, H, W, _ptr(prev), cond.data_ptr(), cond.shape[-1],
                                     _ptr(mask_out), _stream()), "gg_mask_to_cond_slice")
+
+
+def zoom0_index(n_in: int, n_out: int) -> torch.Tensor:
+    """Host-side index map of scipy.ndimage.zoom(order=0) along one axis (the rule gg_mask_to_cond_slice applies on the device):
+    output o reads input floor(o * (n_in-1)/(n_out-1) + 0.5), IEEE double, product and sum rounded separately."""
+    zf = (n_in - 1) / (n_out - 1) if n_out > 1 else 1.0
+    o = torch.arange(n_out, dtype=torch.float64)
+    return torch.clamp(torch.floor(o * zf + 0.5).long(), 0, n_in - 1)
 
 
 def lincomb4(es, coefs, denom: float, out: torch.Tensor) -> torch.Tensor:

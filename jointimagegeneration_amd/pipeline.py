@@ -66,6 +66,8 @@ class GuideGenPipeline:
         self.stats: Dict[str, float] = {}
         self.use_graph = True
         self._slice_graphs: Dict = {}
+        # spatial reduction of the first stage: f = 2^(levels-1) (8 for ch_mult [1,2,4,4], ..._ae.yaml:41-67)
+        self.latent_factor = 2 ** (ldm.first_stage_model.decoder.num_resolutions - 1)
 
     # ---- stage 1 ------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -80,34 +82,18 @@ class GuideGenPipeline:
         labels, _ = self.ccdm.sample_labels(x_T, cond, init_t)
         return labels
 
-    # ---- stage 2 ------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def sample_ct(self, labels: torch.Tensor, depth: int, hw: int, seed: int, max_slices: Optional[int] = None) -> torch.Tensor:
-        """labels int32 [N,Dm,Hm,Wm] -> CT volume fp32 [N, depth, hw, hw] in [0,1]; slice m conditioned on slice m-1."""
-        ldm, sampler, S = self.ldm, self.sampler, self.ddim_steps
-        dev = labels.device
-        N = labels.shape[0]
-        lat = hw // 8
-        Cz = ldm.channels
-        g = torch.Generator(device=dev).manual_seed(seed)
-        samples = torch.zeros((depth, N, hw, hw), dtype=torch.float32, device=dev)        # slice-major: one slice is contiguous
-        # slices whose upsampled mask is non-empty (sample_diffusion.py:202); python indexing of the reference loop kept
-        Dm = labels.shape[1]
-        nz = (labels != 0).flatten(2).any(-1).any(0)                                       # [Dm]
-        idx = torch.nonzero(nz[(torch.arange(depth, device=dev) * Dm) // depth]).flatten()
-        start, end = (int(idx[0]), int(idx[-1])) if idx.numel() else (1, 0)
-        st = sampler.prepare_state(N, Cz, (lat, lat), dev, Cz)
-        todo = list(range(start - 1, end + 1))
-        if max_slices is not None:
-            todo = todo[:max_slices]
-        # static buffers + hipGraphs for the two per-slice networks (cond-stage encode, first-stage decode)
+    def _slice_engine(self, N: int, hw: int, dev, st) -> Dict:
+        """Static buffers + hipGraphs of the two per-slice networks (cond-stage encode, first-stage decode) for one shape."""
+        ldm = self.ldm
+        lat, Cz = hw // self.latent_factor, ldm.channels
         key = (N, hw, str(dev))
+        token = (id(st), ops.weights_token(ldm.cond_stage_model), ops.weights_token(ldm.first_stage_model))
         sg = self._slice_graphs.get(key)
-        if sg is None:
-            sg = dict(cond_in=torch.empty((N, 1, hw, hw, 32), dtype=torch.bfloat16, device=dev),
-                      z=torch.zeros((N, 1, lat, lat, 32), dtype=torch.bfloat16, device=dev),
-                      ds=torch.empty((N, hw, hw), dtype=torch.float32, device=dev), enc=None, dec=None, mom=None, warmed=False)
-            self._slice_graphs[key] = sg
+        if sg is not None and sg["token"] == token:
+            return sg
+        sg = dict(token=token, cond_in=torch.empty((N, 1, hw, hw, 32), dtype=torch.bfloat16, device=dev),
+                  z=torch.zeros((N, 1, lat, lat, 32), dtype=torch.bfloat16, device=dev),
+                  ds=torch.empty((N, hw, hw), dtype=torch.float32, device=dev), enc=None, dec=None, mom=None, warmed=False)
         cond_in, zbuf = sg["cond_in"], sg["z"]
 
         def encode():
@@ -120,6 +106,61 @@ class GuideGenPipeline:
             sg["ds"].copy_(dec.t[..., 0].reshape(N, hw, hw))
             ops.minmax_normalise(sg["ds"], out=sg["ds"])
 
+        sg["encode"], sg["decode"] = encode, decode
+        self._slice_graphs[key] = sg
+        return sg
+
+    @torch.no_grad()
+    def time_slice_stages(self, N: int = 1, hw: int = 512) -> Dict[str, float]:
+        """HIP-event times (ms) of the three per-slice stages on the engine's own buffers, as the slice loop runs them
+        (captured graphs when enabled): cond-encode, one DDIM step (average over the S steps of a slice), decode."""
+        dev = self.ldm.device
+        lat, Cz = hw // self.latent_factor, self.ldm.channels
+        st = self.sampler.prepare_state(N, Cz, (lat, lat), dev, Cz)
+        sg = self._slice_engine(N, hw, dev, st)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+        def run(g, fn):
+            g.replay() if (self.use_graph and g is not None) else fn()
+
+        sg["cond_in"].zero_()
+        st["x"].normal_()
+        st["unet_in"][..., :Cz].copy_(st["x"])
+        for rep in range(2):                                  # first pass warms, second is timed
+            ev[0].record()
+            run(sg["enc"], sg["encode"])
+            ev[1].record()
+            self.sampler.run_steps(st, None, 0.0, None)
+            ev[2].record()
+            run(sg["dec"], sg["decode"])
+            ev[3].record()
+        torch.cuda.synchronize()
+        return {"encode_ms": ev[0].elapsed_time(ev[1]), "ddim_step_ms": ev[1].elapsed_time(ev[2]) / self.ddim_steps,
+                "decode_ms": ev[2].elapsed_time(ev[3])}
+
+    # ---- stage 2 ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_ct(self, labels: torch.Tensor, depth: int, hw: int, seed: int, max_slices: Optional[int] = None) -> torch.Tensor:
+        """labels int32 [N,Dm,Hm,Wm] -> CT volume fp32 [N, depth, hw, hw] in [0,1]; slice m conditioned on slice m-1."""
+        ldm, sampler, S = self.ldm, self.sampler, self.ddim_steps
+        dev = labels.device
+        N = labels.shape[0]
+        lat = hw // self.latent_factor
+        Cz = ldm.channels
+        g = torch.Generator(device=dev).manual_seed(seed)
+        samples = torch.zeros((depth, N, hw, hw), dtype=torch.float32, device=dev)        # slice-major: one slice is contiguous
+        # slices whose upsampled mask is non-empty (sample_diffusion.py:202); python indexing of the reference loop kept
+        Dm = labels.shape[1]
+        nz = (labels != 0).flatten(2).any(-1).any(0)                                       # [Dm]
+        idx = torch.nonzero(nz[ops.zoom0_index(Dm, depth).to(dev)]).flatten()       # same order-0 rule as the glue kernel
+        start, end = (int(idx[0]), int(idx[-1])) if idx.numel() else (1, 0)
+        st = sampler.prepare_state(N, Cz, (lat, lat), dev, Cz)
+        todo = list(range(start - 1, end + 1))
+        if max_slices is not None:
+            todo = todo[:max_slices]
+        sg = self._slice_engine(N, hw, dev, st)
+        cond_in, encode, decode = sg["cond_in"], sg["encode"], sg["decode"]
+
         t_last = time.time()
         for it, m in enumerate(todo):
             if time.time() - t_last > self.progress_every_s:
@@ -128,9 +169,11 @@ class GuideGenPipeline:
             mm = m % depth
             prev = samples[max(0, m - 1) % depth]
             ops.mask_to_cond_slice(labels, mm, depth, hw, hw, prev, cond_in)
-            x_T = torch.randn((N, 1, lat, lat, Cz), generator=g, device=dev)
+            # drawn in the reference's NCHW element order (ddim.py:124 `torch.randn(shape)`), so that a seeded generator gives
+            # sample_diffusion.sample_cond and this loop the same x_T; stored channels-last (plumbing copies)
+            x_T = torch.randn((N, Cz, lat, lat), generator=g, device=dev).permute(0, 2, 3, 1).reshape(N, 1, lat, lat, Cz)
             st["x"].copy_(x_T)
-            st["unet_in"][..., :Cz].copy_(x_T)                                         # plumbing: fp32 -> bf16 copy of x_T
+            st["unet_in"][..., :Cz].copy_(x_T)                                         # fp32 -> bf16
             if not self.use_graph:
                 encode()
             elif not sg["warmed"]:

@@ -272,3 +272,27 @@ def autoregressive_slices(cond_encode, eps_model_for, decode, wholemask: torch.T
         ds = decode(z)
         samples[:, :, m] = slice_minmax_normalise(ds)
     return samples
+
+
+# ------------------------------------------------------------------------------------------------ stage glue
+def zoom0_index(n_in: int, n_out: int) -> np.ndarray:
+    """Input index read by every output index of `scipy.ndimage.zoom(x, n_out / n_in, order=0)` with scipy's defaults
+    (mode="constant", grid_mode=False) along one axis: scipy's NI_ZoomShift maps output o to the input coordinate
+    cc = o * (n_in - 1) / (n_out - 1) in IEEE double (zoom ratio divided first, then multiplied) and order 0 reads
+    floor(cc + 0.5).  This is the order-0 rule of the reference's stage-glue recipe (latentdiffusion/sample_diffusion.py:200)
+    and is NOT torch's F.interpolate(nearest) rule floor(o * n_in / n_out).  Pinned by tests/golden/glue.npz, which holds
+    index maps produced by scipy.ndimage.zoom itself."""
+    zf = np.float64(n_in - 1) / np.float64(n_out - 1) if n_out > 1 else np.float64(1.0)
+    o = np.arange(n_out, dtype=np.float64)
+    return np.clip(np.floor(o * zf + 0.5).astype(np.int64), 0, n_in - 1)
+
+
+def mask_to_cond_volume(labels: torch.Tensor, out_shape) -> torch.Tensor:
+    """wholemask of the recipe at sample_diffusion.py:199-200 for an integer label volume [D, H, W]:
+    rot90(zoom(mask, target / shape, order=0), dims=(1, 2), k=3) / 255.  -> fp32 [D', H', W']."""
+    D, H, W = out_shape
+    idd = torch.from_numpy(zoom0_index(labels.shape[0], D))
+    ih = torch.from_numpy(zoom0_index(labels.shape[1], H))
+    iw = torch.from_numpy(zoom0_index(labels.shape[2], W))
+    up = labels[idd][:, ih][:, :, iw]
+    return torch.rot90(up, k=3, dims=(1, 2)).float() / 255.0

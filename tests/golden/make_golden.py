@@ -473,7 +473,17 @@ def fx_e2e(dd, oh, un, ldm, which):
         torch.manual_seed(SEED)
         x_T = oh.OneHotCategoricalBCHW(logits=torch.zeros(1, K, R, R, R)).sample()
         cond = torch.zeros(1, 1, R, R, R)
+        # the reference loop hands x_t to the UNet once per step (diffusion_denoising.py:206): record it for teacher forcing
+        states, orig_forward = [], u.forward
+
+        def recording_forward(x, *a, **k):
+            states.append(x.argmax(dim=1).to(torch.uint8).clone())
+            return orig_forward(x, *a, **k)
+        u.forward = recording_forward
         ref_lab = model(x_T, cond)["diffusion_out"].argmax(dim=1)
+        u.forward = orig_forward
+        assert len(states) == T and torch.equal(states[0].long(), x_T.argmax(dim=1))
+        states.append(ref_lab.to(torch.uint8))                  # states[i] = x_{T-i}; states[T] = final labels
         gen = g(SEED); M = R ** 3
         E0 = torch.empty(M, K).exponential_(1, generator=gen)
         tapes = [torch.empty(M, K).exponential_(1, generator=gen) for _ in range(T - 1)]
@@ -487,8 +497,25 @@ def fx_e2e(dd, oh, un, ldm, which):
         my_lab, _ = S.ccdm_chain(unet_probs, xT_lab, K, "cosine", T, tapes, "confidence")
         mism = int((my_lab != ref_lab).sum())
         print(f"  C1 chain: oracle-vs-reference label mismatches = {mism}/{M}")
+        # teacher-forced single steps (first, middle, last sampled, final argmax): reference x_t in -> reference x_{t-1} out;
+        # the oracle must reproduce each of them from the same input and the same tape before the fixture is written
+        step_t = [T, T - 1, T // 2 + 1, 2, 1]
+        _, al, ca = S.ccdm_schedule("cosine", T)
+        tf_mism = []
+        for t in step_t:
+            i = T - t
+            xin = states[i].long()
+            xt = S.one_hot_bchw(xin, K)
+            a, abar = S.ccdm_step_scalars(al, ca, t)
+            pr = torch.clamp(S.theta_post_prob(xt, unet_probs(xt, float(t)), a, abar), min=1e-12)
+            nxt = S.race_sample_labels(pr, tapes[i]) if t > 1 else pr.argmax(dim=1)
+            tf_mism.append(int((nxt != states[i + 1].long()).sum()))
+        print(f"  C1 teacher-forced oracle-vs-reference mismatches per step {step_t}: {tf_mism}")
+        assert max(tf_mism) <= 2, tf_mism
         save("e2e_c1", labels=ref_lab.to(torch.uint8), oracle_mismatches=np.array(mism),
-             hist=torch.bincount(ref_lab.flatten(), minlength=K))
+             hist=torch.bincount(ref_lab.flatten(), minlength=K), step_t=np.array(step_t),
+             step_in=torch.stack([states[T - t][0] for t in step_t]), step_out=torch.stack([states[T - t + 1][0] for t in step_t]),
+             step_oracle_mismatches=np.array(tf_mism))
     if "c2" in which:
         u2 = om.UNetModel(dims=2, image_size=512, in_channels=8, out_channels=4, model_channels=160,
                           attention_resolutions=[8, 4, 2], num_res_blocks=2, channel_mult=[1, 2, 4, 4, 5],
@@ -519,6 +546,43 @@ def fx_e2e(dd, oh, un, ldm, which):
         save("e2e_c2", z=z.half(), c_seed=np.array(2048))
 
 
+def fx_glue():
+    """Stage glue: the recipe of latentdiffusion/sample_diffusion.py:199-200,
+    rot90(scipy.ndimage.zoom(mask, target / shape, order=0), dims=(1, 2), k=3) / 255, run with scipy itself."""
+    from scipy.ndimage import zoom
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import synth_labels
+    out = {}
+    pairs = [(128, 512), (128, 256), (64, 96), (64, 256), (10, 23), (12, 32), (14, 32), (7, 512), (100, 333), (5, 5), (1, 4)]
+    for n_in, n_out in pairs:
+        z = zoom(np.arange(1, n_in + 1, dtype=np.int64), n_out / n_in, order=0)
+        assert z.shape == (n_out,) and z.min() >= 1, (n_in, n_out, z.shape)
+        idx = z - 1
+        assert np.array_equal(idx, S.zoom0_index(n_in, n_out)), f"oracle drift on zoom index {n_in}->{n_out}"
+        out[f"idx_{n_in}_{n_out}"] = idx.astype(np.int32)
+    out["pairs"] = np.array(pairs)
+
+    def recipe(lab, target):
+        zz = zoom(lab, np.array(target) / np.array(lab.shape), order=0)
+        assert zz.shape == tuple(target)
+        return torch.rot90(torch.from_numpy(zz), dims=(1, 2), k=3)
+    # non-integer ratios on every axis, whole result kept
+    lab = synth_labels((10, 12, 14), 12, seed=3)
+    rot = recipe(lab, (23, 32, 32))
+    assert torch.equal(rot.float() / 255.0, S.mask_to_cond_volume(torch.from_numpy(lab), (23, 32, 32)))
+    out["small_rot_labels"] = rot.to(torch.uint8)
+    # BASELINE size 128^3 -> 256 x 512 x 512: position-sensitive per-slice checksums (the GPU test also recomputes the
+    # recipe with scipy on the box and compares every voxel)
+    lab = synth_labels((128, 128, 128), 12, seed=7)
+    rot = recipe(lab, (256, 512, 512)).long()
+    assert torch.equal(rot.float() / 255.0, S.mask_to_cond_volume(torch.from_numpy(lab), (256, 512, 512)))
+    i = torch.arange(512)[:, None]; j = torch.arange(512)[None, :]
+    wgt = ((i * 7 + j * 13) % 31 + 1).long()
+    out["full_slice_sum"] = rot.sum((1, 2))
+    out["full_slice_wsum"] = (rot * wgt[None]).sum((1, 2))
+    save("glue", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"small"}
     dd, oh, un, unet_ccdm, nn_ccdm = import_ccdm()
@@ -531,6 +595,8 @@ if __name__ == "__main__":
         print("unets"); fx_unets(un, ldm)
         print("chains"); fx_chains(dd, oh, un, ldm)
         print("surfaces"); fx_full_surfaces(un, ldm)
+    if "glue" in which or "small" in which or "all" in which:
+        print("glue"); fx_glue()
     if "c1" in which or "all" in which:
         fx_e2e(dd, oh, un, ldm, {"c1"})
     if "c2" in which or "all" in which:

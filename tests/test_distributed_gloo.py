@@ -68,3 +68,42 @@ def test_nifti_writer_roundtrip(tmp_path):
     assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:347] == b"n+1"
     assert struct.unpack_from("<8h", raw, 40)[:4] == (3, 4, 3, 2)
     assert np.array_equal(np.frombuffer(raw[352:], dtype=np.uint8).reshape(2, 3, 4), a)
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GG_BENCH_T0")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus2_spawns_its_own_ranks():
+    """`bench.py --gpus 2` started WITHOUT a launcher becomes a parent that starts 2 ranks (rehearsed on CPU: gloo ranks, no
+    sampling) and forwards rank 0's single JSON line; steps/warmup are reported as run, with the requested values beside them."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"GG_BENCH_DRY": "1", "GG_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["steps_requested"] == 3 and j["warmup"] == 1 and j["dry_run"] is True
+    assert j["ms_per_step"] * j["steps"] <= j["wall_s_total"] * 1e3
+
+
+def test_bench_budget_bounds_the_timed_volumes():
+    import json
+    r = _run_bench(["--gpus", "1", "--steps", "100000", "--warmup", "5", "--budget-s", "14"], {"GG_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert 1 <= j["steps"] < 100000 and j["steps_requested"] == 100000 and j["wall_s_total"] < 14.0
+
+
+def test_bench_gpus_mismatch_and_failed_rank_are_errors():
+    # a launcher that started the wrong number of ranks
+    r = _run_bench(["--gpus", "4", "--steps", "1"], {"GG_BENCH_DRY": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    # real (non-rehearsal) ranks on a box without a GPU fail, and the parent reports it
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "2", "--steps", "1"], {"GG_DIST_BACKEND": "gloo"})
+        assert r.returncode != 0
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -710,22 +710,56 @@ def test_ldm_pipeline_ddim_chain(dev):
 
 
 # ------------------------------------------------------------------------------------------------ glue + entry points
-def test_mask_to_cond_slice_matches_torch(dev):
+def test_mask_to_cond_slice_matches_scipy_zoom_recipe(dev):
+    """Stage glue, integer path => bit-exact vs the reference recipe rot90(scipy.ndimage.zoom(mask, target/shape, order=0), k=3)/255
+    (latentdiffusion/sample_diffusion.py:199-200): (a) the committed fixture made by scipy in the build container (non-integer
+    ratios on every axis), (b) scipy itself run on the box, (c) the oracle restatement of the index rule."""
+    from scipy.ndimage import zoom
     from jointimagegeneration_amd import ops
-    g = torch.Generator().manual_seed(21)
-    lab = torch.randint(0, 12, (2, 8, 16, 16), generator=g).int()
-    D, H, W = 16, 64, 64
-    up = F.interpolate(lab[:, None].float(), (D, H, W), mode="nearest")[:, 0]            # order-0 upsample
-    rot = torch.rot90(up, k=3, dims=(2, 3)) / 255.0                                       # sample_diffusion.py:199-200
-    prev = torch.rand(2, H, W, generator=g)
+    from util import synth_labels
+    g = gold("glue")
+    lab = torch.from_numpy(synth_labels((10, 12, 14), 12, seed=3)).int()
+    D, H, W = 23, 32, 32
+    want = T(g["small_rot_labels"]).float() / 255.0                                       # [D, H, W], made by scipy.zoom + rot90
+    live = torch.rot90(torch.from_numpy(zoom(lab.numpy(), np.array((D, H, W)) / np.array(lab.shape), order=0)), dims=(1, 2), k=3).float() / 255.0
+    assert torch.equal(want, live) and torch.equal(want, S.mask_to_cond_volume(lab.long(), (D, H, W)))
+    lab2 = torch.stack([lab, torch.flip(lab, dims=(0, 1))])                                # batch of 2 different volumes
+    want2 = torch.stack([want, S.mask_to_cond_volume(lab2[1].long(), (D, H, W))])
+    gen = torch.Generator().manual_seed(21)
+    prev = torch.rand(2, H, W, generator=gen)
     cond = torch.empty(2, 1, H, W, 32, dtype=torch.bfloat16, device=dev)
     mo = torch.empty(2, H, W, device=dev)
-    for m in (0, 5, 15):
-        ops.mask_to_cond_slice(lab.to(dev), m, D, H, W, prev.to(dev), cond, mask_out=mo)
-        assert torch.equal(mo.cpu(), rot[:, m])
-        assert torch.equal(cond[:, 0, :, :, 1].float().cpu(), rot[:, m].bfloat16().float())
+    for m in range(D):
+        ops.mask_to_cond_slice(lab2.to(dev), m, D, H, W, prev.to(dev), cond, mask_out=mo)
+        assert torch.equal(mo.cpu(), want2[:, m]), m
+        assert torch.equal(cond[:, 0, :, :, 1].float().cpu(), want2[:, m].bfloat16().float())
         assert torch.equal(cond[:, 0, :, :, 0].float().cpu(), prev.bfloat16().float())
         assert float(cond[..., 2:].float().abs().max()) == 0.0
+    # the rule differs from F.interpolate(nearest) (which round 1 had implemented): make sure the test can tell them apart
+    up = F.interpolate(lab[None, None].float(), (D, H, W), mode="nearest")[0, 0]
+    assert not torch.equal(torch.rot90(up, k=3, dims=(1, 2)) / 255.0, want)
+
+
+def test_mask_to_cond_slice_full_size(dev):
+    """BASELINE size: 128^3 CCDM labels -> 256 slices of 512x512; every voxel against scipy.ndimage.zoom run on the box, and the
+    per-slice position-weighted checksums against the fixture written in the build container."""
+    from scipy.ndimage import zoom
+    from jointimagegeneration_amd import ops
+    from util import synth_labels
+    g = gold("glue")
+    lab_np = synth_labels((128, 128, 128), 12, seed=7)
+    D, H, W = 256, 512, 512
+    live = torch.rot90(torch.from_numpy(zoom(lab_np, np.array((D, H, W)) / np.array(lab_np.shape), order=0)), dims=(1, 2), k=3)
+    lab = torch.from_numpy(lab_np).int()[None].to(dev)
+    cond = torch.empty(1, 1, H, W, 32, dtype=torch.bfloat16, device=dev)
+    vol = torch.empty(D, H, W, device=dev)
+    for m in range(D):
+        ops.mask_to_cond_slice(lab, m, D, H, W, None, cond, mask_out=vol[m:m + 1])
+    got = torch.round(vol * 255.0).long().cpu()
+    assert torch.equal(vol.cpu(), live.float() / 255.0)
+    i = torch.arange(512)[:, None]; j = torch.arange(512)[None, :]
+    wgt = ((i * 7 + j * 13) % 31 + 1).long()
+    assert torch.equal(got.sum((1, 2)), T(g["full_slice_sum"])) and torch.equal((got * wgt[None]).sum((1, 2)), T(g["full_slice_wsum"]))
 
 
 def test_entry_points_run_on_small_configs(dev, tmp_path):

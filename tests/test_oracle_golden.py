@@ -232,3 +232,34 @@ def test_small_chains():
     # vanilla ancestral sampling (p_sample_loop) on a 20-step schedule
     zv = S.ddpm_ancestral_sample(eps, T(g["ldm_x_T"]), list(T(g["ldm_vanilla_noises"])), S.ldm_linear_betas(20, 0.0015, 0.0195))
     assert torch.allclose(zv, T(g["ldm_vanilla_z"]), atol=3e-4 * float(np.abs(g["ldm_vanilla_z"]).max()))
+
+
+def test_zoom_order0_index_rule_matches_scipy_fixture():
+    """oracle.samplers.zoom0_index == the index maps scipy.ndimage.zoom(order=0) produced in the build container (glue.npz), and
+    == scipy here; the whole small recipe volume is reproduced; F.interpolate's floor rule is a DIFFERENT map."""
+    from scipy.ndimage import zoom
+    from util import synth_labels
+    g = gold("glue")
+    for n_in, n_out in g["pairs"]:
+        n_in, n_out = int(n_in), int(n_out)
+        idx = S.zoom0_index(n_in, n_out)
+        assert np.array_equal(idx, g[f"idx_{n_in}_{n_out}"])
+        assert np.array_equal(idx, zoom(np.arange(1, n_in + 1), n_out / n_in, order=0) - 1)
+    assert (S.zoom0_index(128, 512) != (np.arange(512) * 128) // 512).mean() > 0.1
+    lab = torch.from_numpy(synth_labels((10, 12, 14), 12, seed=3))
+    assert torch.equal(S.mask_to_cond_volume(lab, (23, 32, 32)), T(g["small_rot_labels"]).float() / 255.0)
+
+
+def test_c1_fixture_holds_teacher_forced_steps():
+    g = gold("e2e_c1")
+    assert list(g["step_t"]) == [50, 49, 26, 2, 1] and g["step_in"].shape == (5, 32, 32, 32) and g["step_out"].shape == (5, 32, 32, 32)
+    assert int(g["step_oracle_mismatches"].max()) == 0                 # the oracle reproduced every stored reference step
+    assert np.array_equal(g["step_out"][-1], g["labels"][0])           # last step's output = the chain's final labels
+    assert np.array_equal(g["step_out"][0], g["step_in"][1])           # t=50's output is t=49's input
+
+
+def test_product_host_zoom_index_equals_oracle():
+    from jointimagegeneration_amd import ops
+    g = gold("glue")
+    for n_in, n_out in g["pairs"]:
+        assert np.array_equal(ops.zoom0_index(int(n_in), int(n_out)).numpy(), g[f"idx_{int(n_in)}_{int(n_out)}"])

@@ -53,3 +53,17 @@ def rel_err(a, b):
 def rms_err(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float(torch.sqrt(((a - b) ** 2).mean()) / (torch.sqrt((b ** 2).mean()) + 1e-30))
+
+
+def synth_labels(shape, n_labels=12, seed=0):
+    """Deterministic nested-ellipsoid label volume [D, H, W] int64 (labels 0..n_labels-1) used by the stage-glue fixtures and
+    the pipeline tests; pure integer / float64 numpy so that it is identical in the build container and on the GPU box."""
+    D, H, W = shape
+    z, y, x = np.meshgrid(np.arange(D, dtype=np.float64), np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    lab = np.zeros(shape, dtype=np.int64)
+    rs = np.random.RandomState(seed)
+    for k in range(1, n_labels):
+        c = (rs.uniform(0.3, 0.7) * D, rs.uniform(0.3, 0.7) * H, rs.uniform(0.3, 0.7) * W)
+        r = (rs.uniform(0.08, 0.3) * D + 1, rs.uniform(0.08, 0.3) * H + 1, rs.uniform(0.08, 0.3) * W + 1)
+        lab[((z - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((x - c[2]) / r[2]) ** 2 <= 1.0] = k
+    return lab
