@@ -63,7 +63,9 @@ typedef struct {
     int32_t out_dtype;         /* GG_BF16 or GG_F32                                                      */
     int32_t prologue_act;      /* fused GroupNorm prologue applied while gathering (zero padding stays zero):
                                   0 none, 1: silu(x*gn_scale + gn_shift), 2: x*gn_scale + gn_shift        */
-    int32_t reserved;
+    int32_t path_hint;         /* 0 = production dispatch.  1 (tests only) = take the halo-tile kernel whenever the shape is inside
+                                  its envelope, even when the grid would under-fill the chip (the production gate then prefers
+                                  the box / split-K kernels): lets small test shapes exercise the kernel the big shapes use */
     const void *src1;          /* bf16 CL [N,D,H,W,C1]                                                   */
     const void *src2;          /* bf16 CL [N,D,H,W,C2] or NULL                                           */
     const void *weight;        /* packed by gg_conv_pack_weight                                          */

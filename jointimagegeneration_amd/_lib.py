@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
         ("N", i32), ("D", i32), ("H", i32), ("W", i32),
         ("C1", i32), ("C2", i32), ("Cout", i32), ("Cout_pad", i32),
         ("kd", i32), ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
-        ("Do", i32), ("Ho", i32), ("Wo", i32), ("out_dtype", i32), ("prologue_act", i32), ("reserved", i32),
+        ("Do", i32), ("Ho", i32), ("Wo", i32), ("out_dtype", i32), ("prologue_act", i32), ("path_hint", i32),
         ("src1", vp), ("src2", vp), ("weight", vp), ("bias", vp), ("bias_stride", i64),
         ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("tile_counters", vp), ("gn_acc", vp),
     ]

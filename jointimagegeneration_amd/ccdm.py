@@ -188,9 +188,7 @@ class DenoisingModel(nn.Module):
                     warmed = True
                 else:
                     if graph is None:                            # capture the fixed-shape step once (hipGraph)
-                        graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):
-                            step(True)
+                        graph = ops.capture_graph(lambda: step(True))
                     graph.replay()
             else:
                 E = None

@@ -6,6 +6,7 @@ struct ConvParams {
     int N, D, H, W, C1, C2, Cout, Cout_pad;
     int kd, kh, kw, stride, pad, upsample;
     int Do, Ho, Wo, out_dtype, prologue_act;
+    int path_hint;            // gg_conv_desc.path_hint (1: tests force the halo kernel below the grid-fill gate)
     int nchunk1, nchunk, ntaps;
     long long M;              // N*Do*Ho*Wo
     long long bias_stride;

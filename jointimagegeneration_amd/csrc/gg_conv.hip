@@ -684,7 +684,7 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
 {
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.Cout = d->Cout; p.Cout_pad = d->Cout_pad;
     p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.upsample = d->upsample;
-    p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.prologue_act = d->prologue_act;
+    p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.out_dtype = d->out_dtype; p.prologue_act = d->prologue_act; p.path_hint = d->path_hint;
     p.nchunk1 = d->C1 / 32; p.nchunk = (d->C1 + d->C2) / 32; p.ntaps = d->kd * d->kh * d->kw;
     p.M = (long long)d->N * d->Do * d->Ho * d->Wo;
     p.bias_stride = d->bias_stride;

@@ -235,6 +235,14 @@ class LitEma(nn.Module):
                 if p.requires_grad:
                     p.copy_(shadow[self.m_name2s_name[key]])
 
+    @torch.no_grad()
+    def reset_from(self, model):
+        """shadow <- current parameters (what LitEma.__init__ does, ema.py:15-22); used after a synthetic re-initialisation."""
+        shadow = dict(self.named_buffers())
+        for key, p in model.named_parameters():
+            if p.requires_grad:
+                shadow[self.m_name2s_name[key]].copy_(p)
+
     def store(self, parameters):
         self.collected_params = [p.detach().clone() for p in parameters]
 
@@ -576,10 +584,7 @@ class DDIMSampler(object):
                     step(None); st["warmed"] = True
                     continue
                 if st["graph"] is None:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        step(None)
-                    st["graph"] = g
+                    st["graph"] = ops.capture_graph(lambda: step(None))
                 st["graph"].replay()
             else:
                 noise = None

@@ -36,6 +36,7 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
 # measured on MI355X: the in-launch combine (agent-scope release per K-slice block) makes the latent UNet forward SLOWER
 # (3.66 vs 2.70 ms) than the separate deterministic reduce launch, so it is off by default; results are bit-identical.
 IN_LAUNCH_SPLITK_COMBINE = False
+PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 to run small shapes on the halo-tile kernel (production: 0)
 _COUNTERS = {}
 
 
@@ -56,6 +57,24 @@ def weights_token(module) -> Tuple[int, int, int]:
         v += p._version
         a += p.data_ptr()
     return n, v, a
+
+
+def capture_graph(fn) -> "torch.cuda.CUDAGraph":
+    """Capture `fn()` (launches on the current stream) into a hipGraph.  The cyclic garbage collector must not run inside the
+    capture: if it frees an older CUDAGraph object there, hipGraphDestroy is refused ("operation not permitted when stream is
+    capturing") inside a destructor and the process aborts.  So: collect first, keep the collector off while capturing."""
+    import gc
+    g = torch.cuda.CUDAGraph()
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g):
+            fn()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return g
 
 
 def pad32(c: int) -> int:
@@ -161,6 +180,7 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
     d.kd, d.kh, d.kw = k
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.path_hint = PATH_HINT
     return bool(lib.gg_conv_fuses_prologue(C.byref(d)))
 
 
@@ -223,6 +243,7 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     d.Do, d.Ho, d.Wo = Do, Ho, Wo
     d.out_dtype = GG_F32 if out.dtype == torch.float32 else GG_BF16
     d.prologue_act = (1 if prologue_silu else 2) if prologue is not None else 0
+    d.path_hint = PATH_HINT
     d.src1 = t1.data_ptr()
     d.src2 = _ptr(src2.t) if src2 is not None else None
     d.weight = weight.data_ptr()

@@ -180,9 +180,7 @@ class GuideGenPipeline:
                 encode()                                                               # eager once: fills the repack cache
             else:
                 if sg["enc"] is None:
-                    sg["enc"] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(sg["enc"]):
-                        encode()
+                    sg["enc"] = ops.capture_graph(encode)
                 sg["enc"].replay()
             sampler.run_steps(st, None, 0.0, None)
             if not self.use_graph:
@@ -192,9 +190,7 @@ class GuideGenPipeline:
                 sg["warmed"] = True
             else:
                 if sg["dec"] is None:
-                    sg["dec"] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(sg["dec"]):
-                        decode()
+                    sg["dec"] = ops.capture_graph(decode)
                 sg["dec"].replay()
             samples[mm].copy_(sg["ds"])
         return samples.permute(1, 0, 2, 3)

@@ -62,6 +62,8 @@ def load_model(config, ckpt):
         print(f"checkpoint {ckpt!r} not found: random-init weights from the seed recipe (synthetic run)", file=sys.stderr)
         model = instantiate_from_config(config["model"])
         randomize_parameters(model, 1024, "ldm.")
+        if getattr(model, "use_ema", False):
+            model.model_ema.reset_from(model.model)        # the EMA shadow is what ema_scope() samples with
         model.cuda().eval()
         global_step = 0
     return model, global_step

@@ -1,6 +1,6 @@
 """GPU suite (-m gpu), BASELINE.json configs C1..C5 at their full network sizes, through the C-ABI, against the CPU oracle and the
 fixtures captured from the imported reference (tests/golden/e2e_c1.npz, e2e_c2.npz), under the PRODUCTION kernel dispatch
-(tests/conftest.py lowers the halo-kernel gates for the toy shapes of test_hip_parity.py; this module restores the defaults).
+(no path hint: the `halo_hint` fixture of tests/conftest.py is only used by kernel-level tests on toy shapes).
 
 Tolerances (stated here, measured values are printed by every test):
   * integer outputs (labels) under teacher forcing: same x_t, same exponential tape => equal labels except where the top-2
@@ -8,7 +8,11 @@ Tolerances (stated here, measured values are printed by every test):
   * probabilities of the categorical head: absolute 4e-2 max, 4e-3 mean; argmax equal wherever the oracle's top-2 margin
     exceeds 8e-2 (2x the max tolerance);
   * eps / latents / decoded images after ONE network pass: 6e-2 of the reference's max magnitude, rms 2e-2;
-  * 50-step DDIM chains (errors accumulate over 50 bf16 forwards): rms 6e-2, max 2.5e-1 of the reference's max magnitude.
+  * 50-step DDIM chains at full size (eta = 0: a contraction, errors do not pile up): rms 1e-2 / max 2e-2 of the reference's max
+    magnitude for C2 (measured 2.4e-3 / 2.2e-3), rms 1.5e-2 / max 3e-2 for C4 (measured 3.4e-3 / 3.4e-3);
+  * a label mismatch under teacher forcing is only accepted where the ORACLE's own decision is a near tie: the top-2 race values
+    p_k / E_k (sampled steps) or probabilities (final argmax) of the oracle differ by less than the tolerance (8e-2 absolute on
+    probabilities = twice the head tolerance; 15 % relative on race values).
 """
 import gzip
 import math
@@ -32,14 +36,6 @@ def dev():
     from jointimagegeneration_amd import _lib
     _lib.load()
     return torch.device("cuda:0")
-
-
-@pytest.fixture(autouse=True)
-def production_dispatch(monkeypatch):
-    """The halo-kernel gates are read once per process from the environment (static locals), so they cannot be flipped back
-    here; instead this module only uses shapes at which the production gates and the test gates choose the same kernels
-    (>= 128 workgroups), and asserts that for the dominant ones."""
-    yield
 
 
 def gen(seed):
@@ -73,7 +69,7 @@ def test_c2_full_ldm_unet_50_ddim_steps_vs_reference_fixture(dev):
         z, _ = s.sample(S=50, batch_size=4, shape=(4, 32, 32), conditioning=c.to(dev), verbose=False, x_T=x_T.to(dev), dims=2, eta=0.0)
         e_max, e_rms = rel_err(z, ref), rms_err(z, ref)
         print(f"C2 (graph={use_graph}): 50-step DDIM latent vs reference: max {e_max:.3e} of max|z|, rms {e_rms:.3e}")
-        assert e_rms < 6e-2 and e_max < 2.5e-1
+        assert e_rms < 1e-2 and e_max < 2e-2
         if use_graph:
             zg = z
     assert torch.equal(zg, z)                        # captured hipGraph == eager launches, bit for bit
@@ -117,9 +113,28 @@ def test_c1_full_ccdm_32_teacher_forced_vs_reference_fixture(dev):
     for j, t in enumerate(step_t):
         trace = []
         model.sample_labels(step_in[j][None].to(dev), cond.to(dev), init_t=t, rng_tapes=tapes[Tn - t:], trace=trace)
-        mism = int((trace[0]["labels"].cpu()[0] != step_out[j]).sum())
-        print(f"C1 teacher-forced step t={t}: {mism} / {M} label mismatches vs the reference (bf16 logits vs fp32)")
-        assert mism <= 0.015 * M
+        bad = (trace[0]["labels"].cpu()[0] != step_out[j])
+        mism = int(bad.sum())
+        # every mismatch must sit on a near tie of the ORACLE's decision values for this step
+        xt = S.one_hot_bchw(step_in[j][None].long(), K)
+        p0 = O.unet_forward(sd, torch.cat([xt, cond], 1), torch.tensor([float(t)]), model_channels=64, head_channels=32, softmax_out=True)
+        a, abar = S.ccdm_step_scalars(*S.ccdm_schedule("cosine", Tn)[1:], t)
+        post = torch.clamp(S.theta_post_prob(xt, p0, a, abar), min=1e-12)[0].permute(1, 2, 3, 0).reshape(M, K)
+        if t > 1:
+            race = post / tapes[Tn - t]
+            top2 = race.topk(2, dim=1).values
+            gap = (top2[:, 0] - top2[:, 1]) / top2[:, 0]
+            worst = float(gap[bad.flatten()].max()) if mism else 0.0
+            tol = 0.15
+        else:
+            post = post / post.sum(-1, keepdim=True)
+            top2 = post.topk(2, dim=1).values
+            gap = top2[:, 0] - top2[:, 1]
+            worst = float(gap[bad.flatten()].max()) if mism else 0.0
+            tol = 8e-2
+        print(f"C1 teacher-forced step t={t}: {mism} / {M} label mismatches vs the reference (bf16 logits vs fp32); "
+              f"largest oracle top-2 gap at a mismatch {worst:.3e} (tolerance {tol})")
+        assert mism <= 0.015 * M and worst < tol
         total += mism
     # (iii) free-running chain (in-kernel Philox): a different random stream, so only the label statistics are comparable
     model.step_T_sample = "majority"
@@ -185,7 +200,7 @@ def test_c4_full_slice_512_cond_encode_ddim_decode_vs_oracle(dev):
         return O.unet_forward(sd_unet, torch.cat([x, ref_c], 1), t, model_channels=160, head_channels=32)
     ref_z, _ = S.ddim_sample(eps, x_T, [torch.zeros_like(x_T)] * 50, m.alphas_cumprod.cpu(), 50)
     print(f"C4 50-step DDIM latent 4x64x64: max {rel_err(z, ref_z):.3e}, rms {rms_err(z, ref_z):.3e}")
-    assert rms_err(z, ref_z) < 6e-2 and rel_err(z, ref_z) < 2.5e-1
+    assert rms_err(z, ref_z) < 1.5e-2 and rel_err(z, ref_z) < 3e-2
     # decode both the oracle's latent (isolates the decoder) and the engine's own latent (the chain as the pipeline runs it)
     ref_dec = O.ae_decode(sd_fs, ref_z)
     dec_iso = m.decode_first_stage(ref_z.to(dev))
@@ -194,7 +209,7 @@ def test_c4_full_slice_512_cond_encode_ddim_decode_vs_oracle(dev):
     dec = m.decode_first_stage(z)
     n_ref, n_got = S.slice_minmax_normalise(ref_dec), S.slice_minmax_normalise(dec.cpu())
     print(f"C4 whole slice (encode -> 50 DDIM -> decode -> min-max): max abs {float((n_got - n_ref).abs().max()):.3e}, rms {rms_err(n_got, n_ref):.3e}")
-    assert rms_err(n_got, n_ref) < 6e-2
+    assert rms_err(n_got, n_ref) < 1.5e-2 and float((n_got - n_ref).abs().max()) < 5e-2
 
 
 # ------------------------------------------------------------------------------------------------ C5: the timed pipeline
@@ -232,7 +247,7 @@ def test_pipeline_sample_ct_equals_reference_shaped_slice_loop(dev, use_graph):
     pipe.sampler.use_graph = use_graph
     lab = synth_labels((5, 16, 16), 12, seed=2)
     lab[0, 3:9, 4:12] = 7                                   # slice 0 non-empty => start_layer = 0 => first m is -1
-    lab[4] = 0                                              # last mask slices empty => the loop stops early
+    lab[3:] = 0                                             # last mask slices empty => the loop stops early
     labels = torch.from_numpy(lab).int()[None].to(dev)
     depth, hw, seed = 7, 32, 4242
     ct = pipe.sample_ct(labels, depth, hw, seed)                                           # [1, depth, hw, hw]

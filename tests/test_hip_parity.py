@@ -83,21 +83,23 @@ HALO_CASES = [
     # name, dims, N, Cin, Cout, spatial(in), upsample   (3x3(x3), stride 1, pad 1; extents tile exactly: halo kernel)
     ("h3d_nt2", 3, 1, 64, 64, (8, 8, 32), False),
     ("h3d_nt4", 3, 2, 32, 128, (4, 8, 16), False),
-    ("h3d_nt3_cin15", 3, 1, 15, 96, (8, 4, 16), False),
+    ("h3d_nt3_cin15", 3, 1, 15, 96, (8, 8, 16), False),
     ("h3d_head_f32", 3, 1, 64, 14, (4, 8, 16), False),
     ("h3d_up", 3, 1, 64, 64, (4, 4, 8), True),
     ("h2d_nt2", 2, 1, 160, 320, (32, 32), False),
-    ("h2d_nt4", 2, 2, 96, 128, (16, 48), False),
+    ("h2d_nt4", 2, 2, 96, 128, (32, 48), False),
     ("h2d_up", 2, 1, 128, 128, (16, 8), True),
     ("h2d_cout1", 2, 1, 128, 1, (32, 16), False),
 ]
 
 
 @pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
-def test_conv_halo_kernel_matches_oracle(dev, case, monkeypatch):
-    """Same oracle, but shapes inside the halo-tile kernel's envelope (GG_HALO_MIN_BLOCKS=1 lifts the grid-size gate)."""
+def test_conv_halo_kernel_matches_oracle(dev, case, halo_hint):
+    """Same oracle, but shapes inside the halo-tile kernel's envelope (path_hint = 1 lifts the grid-fill gate)."""
     from jointimagegeneration_amd import ops
     name, dims, N, Cin, Cout, sp, up = case
+    assert ops.conv_fuses_prologue(ops.CL(torch.empty((N,) + (1,) * (3 - dims) + sp + (ops.pad32(Cin),), dtype=torch.bfloat16, device=dev), Cin),
+                                   Cout, k=(1,) * (3 - dims) + (3,) * dims, upsample=up)        # really the halo kernel
     g = torch.Generator().manual_seed(hash(name) % 1000)
     x = torch.randn((N, Cin) + sp, generator=g)
     w = torch.randn((Cout, Cin) + (3,) * dims, generator=g) / math.sqrt(Cin * 3 ** dims)
@@ -113,7 +115,7 @@ def test_conv_halo_kernel_matches_oracle(dev, case, monkeypatch):
         assert float(out.t[..., Cout:].float().abs().max()) == 0.0
 
 
-def test_conv_halo_two_source_prologue_residual(dev):
+def test_conv_halo_two_source_prologue_residual(dev, halo_hint):
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(6)
     N, C1, C2, Cout, sp = 2, 64, 32, 64, (4, 8, 16)
@@ -609,7 +611,10 @@ def test_blocks_match_reference_fixtures(dev):
     assert rel_err(ops.from_cl(a2.run(ops.to_cl(T(g["aea_x"]).to(dev))), 2), T(g["aea_y"])) < 3e-2
 
 
-def test_small_networks_match_reference_fixtures(dev):
+@pytest.mark.parametrize("hint", [0, 1], ids=["production_dispatch", "halo_hint"])
+def test_small_networks_match_reference_fixtures(dev, hint, monkeypatch):
+    from jointimagegeneration_amd import ops
+    monkeypatch.setattr(ops, "PATH_HINT", hint)
     g = gold("networks_small")
     K, u, u2, u3, ae = build_small()
     u, u2, u3, ae = u.to(dev), u2.to(dev), u3.to(dev), ae.to(dev)
