@@ -19,3 +19,4 @@ def halo_hint(monkeypatch):
     from jointimagegeneration_amd import ops
     monkeypatch.setattr(ops, "PATH_HINT", 1)
     yield
+

@@ -11,8 +11,8 @@ Tolerances (stated here, measured values are printed by every test):
   * 50-step DDIM chains at full size (eta = 0: a contraction, errors do not pile up): rms 1e-2 / max 2e-2 of the reference's max
     magnitude for C2 (measured 2.4e-3 / 2.2e-3), rms 1.5e-2 / max 3e-2 for C4 (measured 3.4e-3 / 3.4e-3);
   * a label mismatch under teacher forcing is only accepted where the ORACLE's own decision is a near tie: the top-2 race values
-    p_k / E_k (sampled steps) or probabilities (final argmax) of the oracle differ by less than the tolerance (8e-2 absolute on
-    probabilities = twice the head tolerance; 15 % relative on race values).
+    p_k / E_k (sampled steps) or probabilities (final argmax) of the oracle differ by less than the tolerance (3e-2 absolute on
+    probabilities; 8 % relative on race values; measured 7e-3 and 2.7e-2).
 """
 import gzip
 import math
@@ -125,13 +125,13 @@ def test_c1_full_ccdm_32_teacher_forced_vs_reference_fixture(dev):
             top2 = race.topk(2, dim=1).values
             gap = (top2[:, 0] - top2[:, 1]) / top2[:, 0]
             worst = float(gap[bad.flatten()].max()) if mism else 0.0
-            tol = 0.15
+            tol = 0.08
         else:
             post = post / post.sum(-1, keepdim=True)
             top2 = post.topk(2, dim=1).values
             gap = top2[:, 0] - top2[:, 1]
             worst = float(gap[bad.flatten()].max()) if mism else 0.0
-            tol = 8e-2
+            tol = 3e-2
         print(f"C1 teacher-forced step t={t}: {mism} / {M} label mismatches vs the reference (bf16 logits vs fp32); "
               f"largest oracle top-2 gap at a mismatch {worst:.3e} (tolerance {tol})")
         assert mism <= 0.015 * M and worst < tol
