@@ -81,11 +81,12 @@ typedef struct {
     int32_t *tile_counters;    /* optional, >= 65536 int32, ZERO on entry and left zero on exit, used by one stream at a time:
                                   enables the in-launch split-K combine (last-arriving K slice reduces + runs the epilogue);
                                   NULL = separate deterministic reduce launch. Results are bit-identical either way. */
-    int64_t *gn_acc;           /* optional [N][4][Cout_pad][2] int64 (4 stripes by position tile, summed by the consumer), caller-zeroed: the epilogue adds, per output channel, the sum
+    int64_t *gn_acc;           /* optional [N][S][Cout_pad][2] int64 (S = gg_conv_emits_stats(desc) stripes by position tile, summed by the consumer), caller-zeroed: the epilogue adds, per output channel, the sum
                                   and the sum of squares of the bf16-rounded outputs in fixed point (2^28 / 2^20 fractional
                                   bits; integer atomics commute, so the result is bit-reproducible).  It is the GroupNorm
-                                  statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc.  Only filled when
-                                  gg_conv_emits_stats(desc) == 1 (box / 160-step kernels without split-K, bf16 output). */
+                                  statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc (4 stripes) or gg_groupnorm_scale_shift_acc.
+                                  Only filled when gg_conv_emits_stats(desc) != 0, which also gives the stripe count (4: box / 160-step
+                                  kernels without split-K; 32: halo-tile kernel); bf16 output only. */
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -100,7 +101,8 @@ int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
 /* 1 if this shape runs on the halo-tile kernel, where the GroupNorm prologue is applied once per staged element (callers
  * then skip the separate gg_groupnorm_apply pass); 0 if it runs on the generic gather kernel. Pointers are not read. */
 int gg_conv_fuses_prologue(const gg_conv_desc *desc);
-/* 1 if gg_conv_forward(desc) will fill desc->gn_acc (see there); pointers are not read. */
+/* 0 if gg_conv_forward(desc) will not fill desc->gn_acc, else the number of stripes S of the [N][S][Cout_pad][2] accumulator it fills
+ * (4 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
 int gg_conv_emits_stats(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);
 
@@ -125,6 +127,13 @@ int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2, int32_t C
 int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2, const int64_t *acc2,
                            int32_t N, int64_t S, int32_t C_logical, const float *gamma, const float *beta, float eps,
                            int32_t act, void *out, void *stream);
+
+/* Per-(n, c) fp32 scale / shift (y = x*scale + shift == GroupNorm(32)(cat[src1, src2])) folded from the accumulators the producing convs
+ * left (acc1 [N][stripes1][C1][2], acc2 [N][stripes2][C2][2] or NULL), for consumers that apply the norm themselves (the halo-tile conv's
+ * fused prologue).  Replaces the gg_groupnorm_stats pass over the tensor. */
+int gg_groupnorm_scale_shift_acc(const int64_t *acc1, int32_t stripes1, int32_t C1, const int64_t *acc2, int32_t stripes2, int32_t C2,
+                                 int32_t N, int64_t S, int32_t C_logical, const float *gamma, const float *beta, float eps,
+                                 float *scale_out, float *shift_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention: out = softmax(scale * Q K^T) V, flash-style (no TxT buffer), MFMA 16x16x32 bf16, fp32 softmax.

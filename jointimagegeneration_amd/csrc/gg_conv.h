@@ -24,6 +24,8 @@ struct ConvParams {
 #define GG_ACC_SQ_SCALE 1048576.0f      /* 2^20 */
 // accumulators are striped [N][GG_ACC_STRIPES][C][2] by position tile, so that at most P/4 workgroups add to one address
 #define GG_ACC_STRIPES 4
+// the halo-tile kernel (thousands of workgroups per launch) stripes 32-way: at most P/32 workgroups add to one address
+#define GG_ACC_STRIPES_HALO 32
 
 // 16-byte chunk swizzle for 64-byte LDS rows read by ds_read_b128 with lane -> (row = r0 + (l&15), chunk = l>>4).
 // chunk ^ ((row>>1)&2) puts the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) on 16

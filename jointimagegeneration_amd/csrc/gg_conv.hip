@@ -720,11 +720,11 @@ extern "C" int gg_conv_emits_stats(const gg_conv_desc *d)
     if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->out_dtype != GG_BF16) return 0;
     ConvParams p;
     fill_params(d, p);
-    if (halo_try_dry(p)) return 0;
-    if (gg_conv_box_try(p, (hipStream_t)-1) == GG_OK) return gg_conv_box_emits_stats(p) ? 1 : 0;
+    if (halo_try_dry(p)) return GG_ACC_STRIPES_HALO;
+    if (gg_conv_box_try(p, (hipStream_t)-1) == GG_OK) return gg_conv_box_emits_stats(p) ? GG_ACC_STRIPES : 0;
     if (gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, p.prologue_act)) return 0;
     const long long osp = (long long)d->Do * d->Ho * d->Wo;
-    return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) == 1 && osp % 64 == 0) ? 1 : 0;
+    return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) == 1 && osp % 64 == 0) ? GG_ACC_STRIPES : 0;
 }
 
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)

@@ -202,6 +202,14 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
 
     // ================= epilogue: + bias[n] (+ residual) -> bf16 / fp32 =================
     const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
+    // GroupNorm statistics of the NEXT norm (gg_conv_desc.gn_acc): per output channel, sum and sum of squares of the bf16-rounded
+    // values this workgroup stores
+    const bool stats = p.gn_acc && p.out_dtype != GG_F32;
+    float ssum[2 * NT][4], ssq[2 * NT][4];
+#pragma unroll
+    for (int a = 0; a < 2 * NT; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         const int tile = wave * TPW + tt;
@@ -226,9 +234,41 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
             } else {
                 bf16x4 ob;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)v[j];
+                for (int j = 0; j < 4; ++j) {
+                    ob[j] = (bf16_t)v[j];
+                    const float f = (float)ob[j];               // what the next norm will read
+                    ssum[ct][j] += f;
+                    ssq[ct][j] += f * f;
+                }
                 *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
             }
+        }
+    }
+    if (stats) {
+        // the 16 positions of a lane row by DPP moves, the waves through LDS in a fixed order (the box / weight image is dead: every
+        // wave has passed the last tap's barrier), then 64-bit fixed-point integer atomics: the sums are exact and order-independent
+        float *statp = reinterpret_cast<float *>(smem);          // [NWAVE][32 * NT couts][sum | sumsq]
+#pragma unroll
+        for (int ct = 0; ct < 2 * NT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = gg_row16_sum(ssum[ct][j]), b = gg_row16_sum(ssq[ct][j]);
+                if (fr == 0) {
+                    float *q = statp + ((wave * (32 * NT) + ct * 16 + fq * 4 + j) << 1);
+                    q[0] = a;
+                    q[1] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 64 * NT) {
+            const int which = tid & 1, c = tid >> 1;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) t += statp[((w * (32 * NT) + c) << 1) + which];
+            const long long fx = __double2ll_rn((double)t * (double)(which ? GG_ACC_SQ_SCALE : GG_ACC_SUM_SCALE));
+            const int stripe = blockIdx.x % GG_ACC_STRIPES_HALO;
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.gn_acc + ((((long long)n * GG_ACC_STRIPES_HALO + stripe) * p.Cout_pad + g0 * 32 + c) * 2 + which)),
+                      (unsigned long long)fx);
         }
     }
 }

@@ -176,14 +176,22 @@ class AutoencoderKL(nn.Module):
 
     # ---- channels-last paths
     def encode_moments_cl(self, x: CL) -> CL:
-        h = self.encoder.run(x)
-        pw, pb = packed_conv(self.quant_conv, h.Cpad)
-        return ops.conv(h, pw, pb, self.quant_conv.weight.shape[0], k=(1, 1, 1), pad=0, out_f32=True)
+        ops.stats_begin(x.t.device)        # conv epilogues leave the GroupNorm sums of the next norm in the (zeroed) arena
+        try:
+            h = self.encoder.run(x)
+            pw, pb = packed_conv(self.quant_conv, h.Cpad)
+            return ops.conv(h, pw, pb, self.quant_conv.weight.shape[0], k=(1, 1, 1), pad=0, out_f32=True)
+        finally:
+            ops.stats_end(x.t.device)
 
     def decode_cl(self, z: CL) -> CL:
-        pw, pb = packed_conv(self.post_quant_conv, z.Cpad)
-        h = ops.conv(z, pw, pb, self.post_quant_conv.weight.shape[0], k=(1, 1, 1), pad=0)
-        return self.decoder.run(h)
+        ops.stats_begin(z.t.device)
+        try:
+            pw, pb = packed_conv(self.post_quant_conv, z.Cpad)
+            h = ops.conv(z, pw, pb, self.post_quant_conv.weight.shape[0], k=(1, 1, 1), pad=0)
+            return self.decoder.run(h)
+        finally:
+            ops.stats_end(z.t.device)
 
     # ---- reference surface (NCHW fp32)
     def encode(self, x: torch.Tensor) -> DiagonalGaussianDistribution:

@@ -86,7 +86,7 @@ class CL:
     """Channels-last activation: t is [N, D, H, W, Cpad] (bf16, or fp32 for head outputs); C = logical channels."""
     t: torch.Tensor
     C: int
-    acc: Optional[torch.Tensor] = None      # int64 [N, 4, Cpad, 2]: striped fixed-point per-channel (sum, sumsq) left by the producing conv
+    acc: Optional[torch.Tensor] = None      # int64 [N, stripes, Cpad, 2]: striped fixed-point per-channel (sum, sumsq) left by the producing conv
 
     @property
     def N(self): return self.t.shape[0]
@@ -213,12 +213,12 @@ def stats_end(device) -> None:
         a["active"] = False
 
 
-def _stats_alloc(device, N: int, cp: int) -> Optional[torch.Tensor]:
+def _stats_alloc(device, N: int, cp: int, stripes: int) -> Optional[torch.Tensor]:
     a = _ARENAS.get(str(device))
-    n = N * 4 * cp * 2                  # 4 stripes (GG_ACC_STRIPES)
+    n = N * stripes * cp * 2            # stripes: 4 (box / 160-step kernels, GG_ACC_STRIPES) or 32 (halo-tile kernel)
     if a is None or not a["active"] or a["off"] + n > _ARENA_ENTRIES:
         return None
-    v = a["buf"][a["off"]:a["off"] + n].view(N, 4, cp, 2)
+    v = a["buf"][a["off"]:a["off"] + n].view(N, stripes, cp, 2)
     a["off"] += n
     return v
 
@@ -260,11 +260,14 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         if IN_LAUNCH_SPLITK_COMBINE:
             d.tile_counters = _tile_counters(t1.device).data_ptr()
     acc = None
-    if (GN_ACC and d.out_dtype == GG_BF16 and GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS
-            and lib.gg_conv_emits_stats(C.byref(d))):
-        acc = _stats_alloc(t1.device, N, cp)
-        if acc is not None:
-            d.gn_acc = acc.data_ptr()
+    if GN_ACC and d.out_dtype == GG_BF16:
+        # box / 160-step kernels (4 stripes): only where the norm is launch-bound; halo-tile kernel (32 stripes): always -- there the
+        # sums replace a statistics PASS over a 17..805 MB tensor
+        stripes = lib.gg_conv_emits_stats(C.byref(d))
+        if stripes == 32 or (stripes and GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS):
+            acc = _stats_alloc(t1.device, N, cp, stripes)
+            if acc is not None:
+                d.gn_acc = acc.data_ptr()
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
     return CL(out, cout, acc)
 
@@ -318,7 +321,31 @@ def groupnorm_apply_acc(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: 
 
 
 def has_stats(src1: CL, src2: Optional[CL] = None) -> bool:
-    return GN_ACC and src1.acc is not None and (src2 is None or src2.acc is not None) and src1.Cpad + (src2.Cpad if src2 is not None else 0) <= 2048
+    """the producing convs left 4-stripe accumulators: gg_groupnorm_apply_acc can normalise without a statistics launch"""
+    ok = lambda c: c is None or (c.acc is not None and c.acc.shape[1] == 4)
+    return GN_ACC and src1.acc is not None and ok(src1) and ok(src2) and src1.Cpad + (src2.Cpad if src2 is not None else 0) <= 2048
+
+
+def has_any_stats(src1: CL, src2: Optional[CL] = None) -> bool:
+    """the producing convs left accumulators (any stripe count): gg_groupnorm_scale_shift_acc replaces the statistics pass"""
+    return GN_ACC and src1.acc is not None and (src2 is None or src2.acc is not None)
+
+
+def groupnorm_scale_shift_acc(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, src2: Optional[CL] = None):
+    """Per-(n, c) fp32 (scale, shift) of GroupNorm(32)(cat[src1, src2]) from the accumulators in CL.acc (no pass over the tensors)."""
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    if src2 is not None and src1.C != C1:
+        raise RuntimeError("two-source GroupNorm needs an unpadded first source")
+    scale = torch.empty((N, C1 + C2), dtype=torch.float32, device=src1.t.device)
+    shift = torch.empty_like(scale)
+    check(lib.gg_groupnorm_scale_shift_acc(src1.acc.data_ptr(), src1.acc.shape[1], C1, src2.acc.data_ptr() if src2 is not None else None,
+                                           src2.acc.shape[1] if src2 is not None else 0, C2, N, S, c_log, gamma.data_ptr(), beta.data_ptr(),
+                                           eps, scale.data_ptr(), shift.data_ptr(), _stream()), "gg_groupnorm_scale_shift_acc")
+    return scale, shift
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

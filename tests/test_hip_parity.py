@@ -437,6 +437,41 @@ def test_conv_epilogue_groupnorm_statistics(dev, cfg, monkeypatch):
         assert rel_err(ops.from_cl(got2, 2), ref2) < 1e-2
 
 
+def test_halo_conv_epilogue_statistics_replace_the_stats_pass(dev, halo_hint):
+    """The halo-tile conv emits, per output channel, the exact fixed-point sum / sum of squares of its bf16-rounded outputs (32
+    stripes); gg_groupnorm_scale_shift_acc folds them into the same per-(n, c) scale / shift the statistics PASS computes, for one
+    source and for the skip concat (two producers, one of them with a residual epilogue), channel padding included."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, sp = 2, (4, 8, 32)
+    x = ops.to_cl(torch.randn((N, 64) + sp, generator=g).to(dev))
+    res = ops.to_cl(torch.randn((N, 96) + sp, generator=g).to(dev))
+    w1 = torch.randn(96, 64, 3, 3, 3, generator=g).to(dev) / math.sqrt(64 * 27)
+    w2 = torch.randn(64, 64, 3, 3, 3, generator=g).to(dev) / math.sqrt(64 * 27)
+    b1 = ops.pad_bias(torch.randn(96, generator=g).to(dev), 96, dev)
+    ops.stats_begin(dev)
+    try:
+        y1 = ops.conv(x, ops.pack_conv_weight(w1, 64), b1, 96, k=(3, 3, 3), residual=res)
+        y2 = ops.conv(x, ops.pack_conv_weight(w2, 64), None, 64, k=(3, 3, 3))
+    finally:
+        ops.stats_end(dev)
+    assert y1.acc is not None and tuple(y1.acc.shape) == (N, 32, 96, 2) and tuple(y2.acc.shape) == (N, 32, 64, 2)
+    # exact integer sums: compare with an fp64 sum of the stored bf16 values
+    s64 = y1.t.double().sum((1, 2, 3))                                                  # [N, 96]
+    got = y1.acc.sum(1)[..., 0].double() / 2.0 ** 28
+    assert float((got - s64).abs().max()) < 1e-3
+    q64 = (y1.t.double() ** 2).sum((1, 2, 3))
+    gotq = y1.acc.sum(1)[..., 1].double() / 2.0 ** 20
+    assert float(((gotq - q64).abs() / q64.abs().clamp_min(1.0)).max()) < 1e-4
+    gam, bet = (1 + 0.1 * torch.randn(160, generator=g)).to(dev), (0.1 * torch.randn(160, generator=g)).to(dev)
+    for a, b2, C in ((y1, None, 96), (y1, y2, 160), (y2, None, 64)):
+        sc_ref, sh_ref = ops.groupnorm_stats(a, gam[:C].contiguous(), bet[:C].contiguous(), 1e-5, b2)
+        sc, sh = ops.groupnorm_scale_shift_acc(a, gam[:C].contiguous(), bet[:C].contiguous(), 1e-5, b2)
+        assert sc.shape == sc_ref.shape
+        assert float((sc - sc_ref).abs().max()) < 2e-5 * float(sc_ref.abs().max()) + 1e-6
+        assert float((sh - sh_ref).abs().max()) < 2e-5 * float(sh_ref.abs().max()) + 1e-5
+
+
 def test_layernorm_geglu_add_linear_embedding(dev):
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(9)
