@@ -139,7 +139,7 @@ def conv_roofline(pipe, device):
            "traffic": None, "launches": len(halo), "avg_launch_ms": round(t / len(halo) * 1e3, 4), "flops_per_launch": round(fl / len(halo)),
            "all_3x3x3_convs": {"launches": len(k27), "achieved": round(fl27 / t27 / 1e12, 1), "flops_per_forward": fl27},
            "eager_forward_ms_with_event_pairs": round(ef0.elapsed_time(ef1), 2)}
-    for name in ("r02_pmc_conv3d.json", "r01_pmc_conv3d.json"):
+    for name in ("r02/pmc_conv3d.json", "r01_pmc_conv3d.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             j = json.load(open(pmc))
