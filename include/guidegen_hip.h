@@ -121,6 +121,12 @@ int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2, int32_t C
 /* y = act(x*scale[n,c] + shift[n,c]) ; act: 0 none, 1 SiLU.  out: bf16 CL [N,S,C1+C2]. */
 int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S,
                        const float *scale, const float *shift, int32_t act, void *out, void *stream);
+/* Statistics + normalise*affine(+SiLU) in ONE launch for small tensors (the <= 16x16 UNet levels): a block keeps its group in registers
+ * between the two phases.  gg_groupnorm_fused_supported says whether (S, C1, C2, C_logical) fits (C_logical == C1 + C2 required);
+ * same result as gg_groupnorm_stats + gg_groupnorm_apply. */
+int gg_groupnorm_fused_supported(int64_t S, int32_t C1, int32_t C2, int32_t C_logical);
+int gg_groupnorm_fused(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S, int32_t C_logical,
+                       const float *gamma, const float *beta, float eps, int32_t act, void *out, void *stream);
 /* The same normalise*affine(+SiLU), with the statistics taken from the per-channel fixed-point accumulators that the producing
  * convs left behind (gg_conv_desc.gn_acc): acc1 [N][4][C1][2], acc2 [N][4][C2][2] (NULL iff C2 == 0).  Every block folds the
  * accumulators into the per-channel scale/shift table in LDS (fp64), so no statistics launch is needed. */

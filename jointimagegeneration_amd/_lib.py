@@ -50,6 +50,8 @@ SIGNATURES = {
     "gg_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i64, vp]),
     "gg_groupnorm_apply": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, vp, i32, vp, vp]),
     "gg_groupnorm_apply_acc": (C.c_int, [vp, i32, vp, vp, i32, vp, i32, i64, i32, vp, vp, f32, i32, vp, vp]),
+    "gg_groupnorm_fused_supported": (C.c_int, [i64, i32, i32, i32]),
+    "gg_groupnorm_fused": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, i32, vp, vp]),
     "gg_groupnorm_scale_shift_acc": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp]),
     "gg_attention_forward": (C.c_int, [C.POINTER(AttentionDesc), vp]),
     "gg_layernorm": (C.c_int, [vp, i64, i32, vp, vp, f32, vp, vp]),

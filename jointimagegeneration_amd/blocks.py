@@ -91,6 +91,8 @@ def f32(p: torch.Tensor) -> torch.Tensor:
 
 
 def gn_silu(h: CL, norm: nn.GroupNorm, act: bool, src2: Optional[CL] = None) -> CL:
+    if ops.groupnorm_fused_ok(h, src2):     # small tensor: statistics + apply in one launch
+        return ops.groupnorm_fused(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
     if ops.has_stats(h, src2):      # the producing convs already left the per-channel sums: no statistics launch
         return ops.groupnorm_apply_acc(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
     scale, shift = ops.groupnorm_stats(h, f32(norm.weight), f32(norm.bias), norm.eps, src2)
@@ -103,6 +105,9 @@ def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Op
     fused into the conv's staging pass (applied once per staged element) -- the activation is never re-written to HBM.
     Gather-kernel convs: separate apply pass (measured: SiLU inside the latency-bound gather loop costs 26 vs 16.6 us/conv)."""
     fused = ops.conv_fuses_prologue(h, cout, src2=src2, **conv_kw)
+    if not fused and ops.groupnorm_fused_ok(h, src2):     # small tensor: statistics + apply in ONE launch
+        a = ops.groupnorm_fused(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
+        return ops.conv(a, weight, bias, cout, **conv_kw)
     if not fused and ops.has_stats(h, src2):     # statistics came with the tensor (conv epilogue accumulators)
         a = ops.groupnorm_apply_acc(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
         return ops.conv(a, weight, bias, cout, **conv_kw)

@@ -175,6 +175,133 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
         for (int c = C_logical + tid; c < C; c += 256) { scale[(long long)n * C + c] = 0.f; shift[(long long)n * C + c] = 0.f; }
 }
 
+// Small tensors, ONE launch for the whole norm: block (g, n) keeps its group's S x cpg elements in registers (as the 16-byte pieces
+// that cover the group's channels; foreign lanes masked), reduces them (fp32 per thread, fp64 butterfly, fixed order), then
+// normalises * affine (* SiLU) the same registers and stores them: interior pieces as 16 bytes, the pieces it shares with the
+// neighbouring groups' blocks element by element (byte-enabled 2-byte stores: no block writes a foreign channel).
+// Replaces gn_stats_small + gn_apply (two dependent launches) at the 8x8 / 4x4 UNet levels only (see gn_fused_small_ok).
+#define GG_GN_FUSED_MAXP 2      /* pieces per thread kept in registers */
+__global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__restrict__ s1, int C1, const bf16_t *__restrict__ s2, int C2,
+                                                             long long S, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float eps, int act, bf16_t *__restrict__ out)
+{
+    const int C = C1 + C2;
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / 32;
+    const bf16_t *b1 = s1 + (long long)n * S * C1;
+    const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
+    bf16_t *o = out + (long long)n * S * C;
+    __shared__ float gb[2][64];                             // gamma / beta of the group's channels (cpg <= 64)
+    if (tid < cpg) { gb[0][tid] = gamma[g * cpg + tid]; gb[1][tid] = beta[g * cpg + tid]; }
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int p_lo = c_lo >> 3, p_hi = (c_hi - 1) >> 3;
+    const int np = p_hi - p_lo + 1;
+    const int work = (int)S * np;
+    u32x4 v[GG_GN_FUSED_MAXP];
+#pragma unroll
+    for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
+        const int i = tid + 256 * k;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (i < work) {
+            const int r = i / np;
+            const int c0 = (p_lo + (i - r * np)) * 8;
+            v[k] = *reinterpret_cast<const u32x4 *>((c0 < C1) ? b1 + (long long)r * C1 + c0 : b2 + (long long)r * C2 + (c0 - C1));
+        }
+    }
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
+        const int i = tid + 256 * k;
+        if (i < work) {
+            const int r = i / np;
+            const int c0 = (p_lo + (i - r * np)) * 8;
+            const bf16x8 x = __builtin_bit_cast(bf16x8, v[k]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j;
+                const float f = (c >= c_lo && c < c_hi) ? (float)x[j] : 0.f;
+                a += f;
+                b += f * f;
+            }
+        }
+    }
+    double da = (double)a, db = (double)b;
+#pragma unroll
+    for (int x = 1; x < 64; x <<= 1) {
+        da += __shfl_xor(da, x);
+        db += __shfl_xor(db, x);
+    }
+    __shared__ double ra[4], rb[4];
+    if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
+    __syncthreads();
+    const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+    const double cnt = (double)S * (double)cpg;
+    const double mean = sa / cnt;
+    double var = sb / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
+        const int i = tid + 256 * k;
+        if (i < work) {
+            const int r = i / np;
+            const int c0 = (p_lo + (i - r * np)) * 8;
+            const bf16x8 x = __builtin_bit_cast(bf16x8, v[k]);
+            bf16x8 y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int cl = c0 + j - c_lo;                         // channel inside the group (clamped for the foreign lanes: not stored)
+                cl = cl < 0 ? 0 : (cl >= cpg ? cpg - 1 : cl);
+                const float sc = frstd * gb[0][cl];             // the same fp32 scale / shift the two-launch path tabulates
+                float t = (float)x[j] * sc + (gb[1][cl] - fmean * sc);
+                if (act) t = gg_silu(t);
+                y[j] = (bf16_t)t;
+            }
+            bf16_t *dst = o + (long long)r * C + c0;
+            if (c0 >= c_lo && c0 + 8 <= c_hi) {
+                *reinterpret_cast<bf16x8 *>(dst) = y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j >= c_lo && c0 + j < c_hi) dst[j] = y[j];
+            }
+        }
+    }
+}
+
+static bool gn_fused_small_ok(long long S, int C1, int C2, int C_logical)
+{
+    const int C = C1 + C2;
+    if (C_logical != C || C % 32 || C / 32 > 64 || S > (1 << 20)) return false;
+    const int cpg = C / 32;
+    int np = 0;                                              // most pieces any group's channel range touches
+    for (int g = 0; g < 32; ++g) {
+        const int n = (((g + 1) * cpg - 1) >> 3) - ((g * cpg) >> 3) + 1;
+        np = n > np ? n : np;
+    }
+    // measured (tools/probe_gn.py, us, two launches vs this kernel): 8x8x640 5.0 vs 4.5, 4x4x800 4.9 vs 4.3, but 16x16x640 5.8 vs 7.2 and
+    // 32x32x320 7.7 vs 14.0: past two pieces per thread the serial work of the 32 blocks costs more than the saved launch
+    return S * np <= 512;
+}
+
+extern "C" int gg_groupnorm_fused_supported(int64_t S, int32_t C1, int32_t C2, int32_t C_logical)
+{
+    return (C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && gn_fused_small_ok(S, C1, C2, C_logical)) ? 1 : 0;
+}
+
+extern "C" int gg_groupnorm_fused(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S, int32_t C_logical,
+                                  const float *gamma, const float *beta, float eps, int32_t act, void *out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (C1 <= 0 || C1 % 32 || C2 % 32 || C2 < 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_fused: C1/C2 must be multiples of 32");
+    if (!src1 || (C2 && !src2) || !gamma || !beta || !out || N <= 0 || S <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "groupnorm_fused: null pointer / empty");
+    if (!gn_fused_small_ok(S, C1, C2, C_logical)) GG_FAIL(GG_ERR_UNSUPPORTED, "groupnorm_fused: tensor too large for the single-launch path (gg_groupnorm_fused_supported)");
+    hipLaunchKernelGGL(gn_fused_small_kernel, dim3(32, N), dim3(256), 0, stream, (const bf16_t *)src1, C1, (const bf16_t *)src2, C2,
+                       (long long)S, gamma, beta, eps, act, (bf16_t *)out);
+    GG_CHECK_LAUNCH();
+    return GG_OK;
+}
+
 extern "C" int64_t gg_groupnorm_workspace_bytes(int32_t N, int64_t S, int32_t C)
 {
     (void)S;

@@ -304,6 +304,27 @@ def groupnorm_apply(src1: CL, scale: torch.Tensor, shift: torch.Tensor, act: boo
     return CL(out, src1.C + (src2.C if src2 is not None else 0))
 
 
+def groupnorm_fused_ok(src1: CL, src2: Optional[CL] = None) -> bool:
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    if src2 is not None and src1.C != src1.Cpad:
+        return False
+    return bool(_lib.load().gg_groupnorm_fused_supported(src1.S, src1.Cpad, C2, c_log))
+
+
+def groupnorm_fused(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool, src2: Optional[CL] = None) -> CL:
+    """act(GroupNorm(32)(cat[src1, src2])) in one launch (small tensors: see groupnorm_fused_ok)."""
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    out = torch.empty(tuple(src1.t.shape[:4]) + (C1 + C2,), dtype=torch.bfloat16, device=src1.t.device)
+    check(lib.gg_groupnorm_fused(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, c_log, gamma.data_ptr(),
+                                 beta.data_ptr(), eps, 1 if act else 0, out.data_ptr(), _stream()), "gg_groupnorm_fused")
+    return CL(out, c_log)
+
+
 def groupnorm_apply_acc(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool, src2: Optional[CL] = None) -> CL:
     """act(GroupNorm(32)(cat[src1, src2])) with the statistics taken from the accumulators the producing convs left in CL.acc."""
     lib = _lib.load()

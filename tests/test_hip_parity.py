@@ -437,6 +437,34 @@ def test_conv_epilogue_groupnorm_statistics(dev, cfg, monkeypatch):
         assert rel_err(ops.from_cl(got2, 2), ref2) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 640, 8, 8), (1, 800, 4, 4), (1, 1440, 8, 8), (1, 320, 8, 16), (3, 160, 7, 9), (1, 1600, 4, 4)])
+def test_groupnorm_fused_single_launch(dev, shape):
+    """One-launch statistics + apply for small tensors == oracle GroupNorm(+SiLU), and == the two-launch path up to bf16 rounding;
+    groups whose channel range shares 16-byte pieces with the neighbours (cpg = 5, 25, 45, 50) and the two-source concat."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 1.7 + 0.3
+    Cc = shape[1]
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xcl = ops.to_cl(x.to(dev))
+    assert ops.groupnorm_fused_ok(xcl)
+    for act in (True, False):
+        ref = O.group_norm(bf(x), gamma, beta, 1e-5)
+        ref = O.silu(ref) if act else ref
+        got = ops.from_cl(ops.groupnorm_fused(xcl, gamma.to(dev), beta.to(dev), 1e-5, act), 2).cpu()
+        assert rel_err(got, ref) < 1e-2
+        sc, sh = ops.groupnorm_stats(xcl, gamma.to(dev), beta.to(dev), 1e-5)
+        two = ops.from_cl(ops.groupnorm_apply(xcl, sc, sh, act), 2).cpu()
+        assert float((got - two).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())       # at most a bf16 ulp or two apart
+    if Cc % 64 == 0:                                                                        # two sources: cat[x[:, :C/2], x[:, C/2:]]
+        a, b2 = ops.to_cl(x[:, :Cc // 2].contiguous().to(dev)), ops.to_cl(x[:, Cc // 2:].contiguous().to(dev))
+        assert ops.groupnorm_fused_ok(a, b2)
+        got2 = ops.from_cl(ops.groupnorm_fused(a, gamma.to(dev), beta.to(dev), 1e-5, True, b2), 2).cpu()
+        assert torch.equal(got2, ops.from_cl(ops.groupnorm_fused(xcl, gamma.to(dev), beta.to(dev), 1e-5, True), 2).cpu())
+    big = ops.CL(torch.zeros(1, 1, 64, 64, 320, dtype=torch.bfloat16, device=dev), 320)
+    assert not ops.groupnorm_fused_ok(big)
+
+
 def test_halo_conv_epilogue_statistics_replace_the_stats_pass(dev, halo_hint):
     """The halo-tile conv emits, per output channel, the exact fixed-point sum / sum of squares of its bf16-rounded outputs (32
     stripes); gg_groupnorm_scale_shift_acc folds them into the same per-(n, c) scale / shift the statistics PASS computes, for one

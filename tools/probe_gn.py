@@ -20,7 +20,9 @@ def only_apply(sc_sh=ops.groupnorm_stats(y, gamma, beta, 1e-5)):
     return ops.groupnorm_apply(y, sc_sh[0], sc_sh[1], True)
 def new():
     return ops.groupnorm_apply_acc(y, gamma, beta, 1e-5, True)
-cases = [("stats+apply", old), ("apply only", only_apply)] + ([("apply_acc", new)] if y.acc is not None else [])
+def fused():
+    return ops.groupnorm_fused(y, gamma, beta, 1e-5, True)
+cases = [("stats+apply", old), ("apply only", only_apply)] + ([("fused one-launch", fused)] if ops.groupnorm_fused_ok(y) else []) + ([("apply_acc", new)] if y.acc is not None else [])
 for name, f in cases:
     f(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
