@@ -78,9 +78,7 @@ typedef struct {
     const float *gn_shift;
     void *workspace;           /* caller-owned scratch (split-K slabs); size from gg_conv_workspace_bytes */
     int64_t workspace_bytes;
-    int32_t *tile_counters;    /* optional, >= 65536 int32, ZERO on entry and left zero on exit, used by one stream at a time:
-                                  enables the in-launch split-K combine (last-arriving K slice reduces + runs the epilogue);
-                                  NULL = separate deterministic reduce launch. Results are bit-identical either way. */
+    void *reserved_ptr;        /* must be NULL (was: tickets of an in-launch split-K combine, measured slower and removed) */
     int64_t *gn_acc;           /* optional [N][S][Cout_pad][2] int64 (S = gg_conv_emits_stats(desc) stripes by position tile, summed by the consumer), caller-zeroed: the epilogue adds, per output channel, the sum
                                   and the sum of squares of the bf16-rounded outputs in fixed point (2^28 / 2^20 fractional
                                   bits; integer atomics commute, so the result is bit-reproducible).  It is the GroupNorm

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("kd", i32), ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
         ("Do", i32), ("Ho", i32), ("Wo", i32), ("out_dtype", i32), ("prologue_act", i32), ("path_hint", i32),
         ("src1", vp), ("src2", vp), ("weight", vp), ("bias", vp), ("bias_stride", i64),
-        ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("tile_counters", vp), ("gn_acc", vp),
+        ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("reserved_ptr", vp), ("gn_acc", vp),
     ]
 
 

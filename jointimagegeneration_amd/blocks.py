@@ -121,18 +121,6 @@ def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Op
     return ops.conv(a, weight, bias, cout, **conv_kw)
 
 
-SIDE_STREAM_SKIP = False                      # measured: fork/join edges in the hipGraph cost more than the overlap saves (3.03 vs 2.69 ms)
-SIDE_STREAM_MAX_POSITIONS = 1 << 16          # only where launches, not bandwidth, dominate (latent UNet, deep levels)
-_SIDE = {}
-
-
-def _side_stream(device) -> torch.cuda.Stream:
-    key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
-
-
 class TimestepBlock(nn.Module):
     pass
 
@@ -204,25 +192,16 @@ class ResBlock(TimestepBlock):
         c1, c2 = self.in_layers[2], self.out_layers[3]
         k = _k3(c1.weight)
         cin_pad = h.Cpad + (src2.Cpad if src2 is not None else 0)
-        # the 1x1 skip projection only depends on the block input: run it on a side stream so that it overlaps the
-        # GN -> conv1 -> GN chain (captured as a fork/join inside the hipGraph); it joins before conv2's residual epilogue
-        res, side = h, None
+        # (running the 1x1 skip projection on a side stream beside the GN -> conv1 -> GN chain was measured slower: the fork / join
+        # edges in the hipGraph cost more than the overlap saves, 3.03 vs 2.69 ms per latent-UNet forward)
+        res = h
         if not isinstance(self.skip_connection, nn.Identity):
             pws, pbs = packed_conv(self.skip_connection, cin_pad)
             ks = _k3(self.skip_connection.weight)
-            if SIDE_STREAM_SKIP and h.N * h.S <= SIDE_STREAM_MAX_POSITIONS:
-                main = torch.cuda.current_stream()
-                side = _side_stream(h.t.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
-            else:
-                res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
+            res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
         pw1, _ = packed_conv(c1, cin_pad)
         h1 = norm_conv(h, self.in_layers[0], True, pw1, tbias, self.out_channels, src2=src2, k=k, bias_per_sample=True)
         pw2, pb2 = packed_conv(c2, h1.Cpad)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
         return norm_conv(h1, self.out_layers[0], True, pw2, pb2, self.out_channels, k=k, residual=res)
 
 

@@ -14,7 +14,6 @@ struct ConvParams {
     const float *bias, *gn_scale, *gn_shift;
     void *out;
     float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
-    int *counters;            // per output tile arrival tickets (zero on entry, zero on exit) or nullptr
     int splitk;
     long long *gn_acc;        // per-channel fixed-point (sum, sumsq) accumulators of the outputs [N][Cout_pad][2], or nullptr
 };

@@ -309,17 +309,12 @@ struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long lon
 // 256 CUs.  Smallest wins; ties go to the larger tile (fewer redundant halo bytes overall).
 static bool plan_box(const ConvParams &p, BoxPlan &pl)
 {
-    static const int enabled = [] { const char *e = getenv("GG_BOX2D"); return e ? atoi(e) : 1; }();
-    static const long long max_blocks = [] { const char *e = getenv("GG_BOX2D_MAXBLK"); return e ? atoll(e) : 1024LL; }();
-    static const long long lds_cap = [] { const char *e = getenv("GG_BOX2D_LDS"); return e ? atoll(e) : 131072LL; }();
-    static const int force_th = [] { const char *e = getenv("GG_BOX2D_TH"); return e ? atoi(e) : 0; }();
-    static const int force_ct = [] { const char *e = getenv("GG_BOX2D_CT"); return e ? atoi(e) : 0; }();
-    if (!enabled) return false;
+    constexpr long long max_blocks = 1024, lds_cap = 131072;     // <= 4 rounds of 256 workgroups; box + GroupNorm rows <= 128 KiB
     const bool k3 = p.kh == 3 && p.kw == 3 && p.pad == 1, k1 = p.kh == 1 && p.kw == 1 && p.pad == 0 && !p.upsample;
     if (!(p.kd == 1 && p.D == 1 && p.stride == 1 && (k3 || k1))) return false;
     const int halo = k3 ? 2 : 0;
     // 1x1: only where the grid is under-filled (measured: 8x8 4.2 vs 8.6 us on the tiny-M kernel, but 64x64 12.0 vs 7.8 us on gather5)
-    static const long long k1_max_m = [] { const char *e = getenv("GG_BOX2D_K1_MAXM"); return e ? atoll(e) : 256LL; }();
+    constexpr long long k1_max_m = 256;
     if (k1 && p.M > k1_max_m) return false;
     const int TWI = p.Wo % 16 == 0 ? 16 : p.Wo % 8 == 0 ? 8 : p.Wo % 4 == 0 ? 4 : 0;   // width of a 16-position MFMA tile
     if (!TWI) return false;
@@ -329,17 +324,14 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     int bMT = 0, bCT = 0;
     // tile heights: powers of two, plus 12 / 6 / 3 rows for 16-wide tiles so that 240 (not 160 or 320) workgroups cover the
     // 64 / 32 / 16-row levels; the last row tile may be ragged (rows >= Ho are computed on zero padding and not stored)
-    static const int ragged_on = [] { const char *e = getenv("GG_BOX2D_RAGGED"); return e ? atoi(e) : 1; }();
     for (int MT : {12, 8, 6, 4, 3, 2, 1}) {
         const int TH = MT * RPT;
-        if (!ragged_on && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
-        if ((p.upsample && (TH & 1)) || TH > p.Ho || (force_th && MT != force_th)) continue;
+        if ((p.upsample && (TH & 1)) || TH > p.Ho) continue;
         if (TWI != 16 && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
         if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
         const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
-            if (force_ct && CT != force_ct) continue;
             const long long blocks = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
             if (blocks > max_blocks || 8LL * MT * CT * 1024 > lds_cap) continue;      // grid cap; the 8-wave combine area must fit
             // every extra LDS stage is another exposed staging round trip
@@ -411,7 +403,7 @@ static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stre
 // cout tiles share a box (measured: Q = 5 breaks even with the 3 us apply launch, Q = 20 costs +6 us).
 bool gg_conv_box_fuses_prologue(const ConvParams &p)
 {
-    static const int fuse_q = [] { const char *e = getenv("GG_BOX2D_FUSE_Q"); return e ? atoi(e) : 2; }();
+    constexpr int fuse_q = 2;
     BoxPlan pl;
     if (!plan_box(p, pl)) return false;
     return p.Cout_pad / (16 * pl.CT) <= fuse_q;

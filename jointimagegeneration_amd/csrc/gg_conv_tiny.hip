@@ -171,8 +171,7 @@ static void launch_tiny(const ConvParams &p, hipStream_t stream)
 // plan: 0 = not applicable, else the K split
 int gg_conv_tiny_plan(long long M, int Cout_pad, int KS, int prologue_act)
 {
-    static const int enabled = [] { const char *e = getenv("GG_TINYM"); return e ? atoi(e) : 1; }();
-    if (!enabled || M > 128 || prologue_act) return 0;
+    if (M > 128 || prologue_act) return 0;
     const int G = Cout_pad / 32;
     long long want = (768 + G - 1) / G;              // ~3 workgroups per CU
     long long maxs = KS / 16 > 0 ? KS / 16 : 1;      // >= 16 k-steps per workgroup (4 per wave)

@@ -33,21 +33,7 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
                            "(no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")
 
 
-# measured on MI355X: the in-launch combine (agent-scope release per K-slice block) makes the latent UNet forward SLOWER
-# (3.66 vs 2.70 ms) than the separate deterministic reduce launch, so it is off by default; results are bit-identical.
-IN_LAUNCH_SPLITK_COMBINE = False
 PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 to run small shapes on the halo-tile kernel (production: 0)
-_COUNTERS = {}
-
-
-def _tile_counters(device) -> torch.Tensor:
-    """Persistent zero-initialised arrival tickets (one buffer per device; kernels leave it zero)."""
-    key = str(device)
-    if key not in _COUNTERS:
-        _COUNTERS[key] = torch.zeros(65536, dtype=torch.int32, device=device)
-    return _COUNTERS[key]
-
-
 def weights_token(module) -> Tuple[int, int, int]:
     """Cheap identity of a module's current weights: (#tensors, sum of in-place version counters, sum of storage addresses).
     load_state_dict, LitEma.copy_to / restore and optimizer steps write in place (version bump); .to(device) moves storage."""
@@ -186,9 +172,9 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 
 # ---- GroupNorm statistics emitted by conv epilogues (gg_conv_desc.gn_acc).  One int64 arena per device, bump-allocated per
 # network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
-GN_ACC = os.environ.get("GG_GN_ACC", "1") != "0"
+GN_ACC = True
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
-GN_ACC_MIN_ELEMS = int(os.environ.get("GG_GN_ACC_MIN", str(1 << 18)))   # below this the one-launch statistics kernel is as fast (5 us)
+GN_ACC_MIN_ELEMS = 1 << 18          # below this the one-launch statistics kernel is as fast (5 us)
 _ARENA_ENTRIES = 1 << 19            # 4 MiB of int64 (the latent UNet at batch 1 uses ~0.4 M entries)
 _ARENAS = {}
 
@@ -257,8 +243,6 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     if wsb > 0:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=t1.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
-        if IN_LAUNCH_SPLITK_COMBINE:
-            d.tile_counters = _tile_counters(t1.device).data_ptr()
     acc = None
     if GN_ACC and d.out_dtype == GG_BF16:
         # box / 160-step kernels (4 stripes): only where the norm is launch-bound; halo-tile kernel (32 stripes): always -- there the

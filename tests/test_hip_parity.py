@@ -164,10 +164,8 @@ def test_conv_two_source_residual_per_sample_bias_prologue(dev):
     assert rel_err(ops.from_cl(out2, 3), ref) < 1.5e-2
 
 
-def test_splitk_in_launch_combine_is_bit_identical_and_self_cleaning(dev):
-    """Under-filled convs are split over K. The in-launch combine (last-arriving slice reduces, agent-scope release/acquire)
-    must equal the separate deterministic reduce launch bit for bit, on every one of many back-to-back launches with the
-    consumer's caches warm, and must leave the ticket buffer zero."""
+def test_splitk_reduce_is_deterministic(dev):
+    """Under-filled convs are split over K; the slab reduce runs in a fixed order: every launch gives the same bits."""
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(12)
     for (N, Cin, Cout, sp) in ((1, 1600, 800, (4, 4)), (1, 320, 160, (20, 20)), (2, 640, 320, (12, 12))):
@@ -175,14 +173,10 @@ def test_splitk_in_launch_combine_is_bit_identical_and_self_cleaning(dev):
         w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
         res = ops.to_cl(torch.randn((N, Cout) + sp, generator=g).to(dev))
         pw, pb = ops.pack_conv_weight(w.to(dev), Cin), ops.pad_bias(torch.randn(Cout, generator=g).to(dev), Cout, dev)
-        ops.IN_LAUNCH_SPLITK_COMBINE = False
         ref = ops.conv(x, pw, pb, Cout, k=(1, 3, 3), residual=res).t.clone()
-        ops.IN_LAUNCH_SPLITK_COMBINE = True
-        outs = [ops.conv(x, pw, pb, Cout, k=(1, 3, 3), residual=res).t for _ in range(200)]
+        outs = [ops.conv(x, pw, pb, Cout, k=(1, 3, 3), residual=res).t for _ in range(50)]
         torch.cuda.synchronize()
         assert all(torch.equal(o, ref) for o in outs)
-        assert int(ops._tile_counters(dev).abs().sum()) == 0
-    ops.IN_LAUNCH_SPLITK_COMBINE = False
 
 
 def test_conv_gather5_two_source_prologue_residual(dev):

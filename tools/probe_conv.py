@@ -30,4 +30,4 @@ for _ in range(5): g.replay()
 torch.cuda.synchronize()
 t = (time.time() - t0) / 250
 gf = 2.0 * N * H * W * Cout * Cin * k * k / 1e9
-print(f"conv N={N} {Cin}->{Cout} {H}x{W} k={k}: {t*1e6:.1f} us/conv ({gf/t/1e3:.1f} TFLOP/s) pro={os.environ.get('PROBE_PRO')} box={os.environ.get('GG_BOX2D')} minblk={os.environ.get('GG_BOX2D_MINBLK')}")
+print(f"conv N={N} {Cin}->{Cout} {H}x{W} k={k}: {t*1e6:.1f} us/conv ({gf/t/1e3:.1f} TFLOP/s) pro={os.environ.get('PROBE_PRO')}")
