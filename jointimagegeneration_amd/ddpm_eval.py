@@ -20,6 +20,7 @@ import yaml
 
 from . import distributed as ggd
 from .ccdm import build_model
+from .encoder import build_feature_cond_encoder
 from .io import load_checkpoint, write_nifti
 from .synth import randomize_parameters
 
@@ -78,6 +79,23 @@ def main(argv=None):
     model = build_from_params(params, size, K).eval()
     load_weights(model, params, log=lambda m: print(f"[rank {rank}] {m}", file=sys.stderr))
     model = model.to(dev)
+    # text conditioning (evaluator.py:166-169): the 'selfattn' feature encoder runs over the cached BERT features of the volume;
+    # synthetic features here (the hospital reports are private).  The shipped UNet has no SpatialTransformer and ignores the
+    # resulting context, exactly as in the reference.
+    fce = build_feature_cond_encoder(params)
+    context = None
+    if fce is not None:
+        path = params.get("load_from")
+        if path and os.path.exists(path):
+            ck = load_checkpoint(path)
+            sd_fce = ck.get("average_feature_cond_encoder", ck.get("feature_cond_encoder"))
+            if sd_fce is not None:
+                fce.load_state_dict(sd_fce)
+        else:
+            randomize_parameters(fce, 1024, "fce.")
+        fce = fce.eval().to(dev)
+        feats = torch.randn((1, fce.embed_dim, int(params.get("context_length", 512))), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
+        context = fce(feats)
     out_dir = args.out or os.path.join(params.get("output_path", "."), args.exp_name)
     os.makedirs(out_dir, exist_ok=True)
     init_t = None if args.steps is None else 10000 + args.steps

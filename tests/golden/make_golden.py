@@ -583,6 +583,20 @@ def fx_glue():
     save("glue", **out)
 
 
+def fx_text_encoder():
+    """PreloadedBERTEncoder (ccdm/ddpm/models/encoder.py:103-123) at its shipped size (768, 8 heads x 64, depth 4)
+    on cached-feature-shaped random inputs [2, 768, 40], eval mode; reference output + oracle cross-check."""
+    enc = importlib.import_module("ddpm.models.encoder")
+    m = enc.PreloadedBERTEncoder(embed_dim=768, n_heads=8, depth=4, d_head=64, dropout=0.1).eval()
+    randomize_parameters(m, SEED, "bertenc.")
+    feats = torch.randn(2, 768, 40, generator=g(31))
+    ref = m(feats)
+    mine = O.preloaded_bert_encoder(sd_of(m), feats, 8)
+    err = close(mine, ref, 2e-5, "PreloadedBERTEncoder")
+    print(f"  text encoder: oracle-vs-reference max|d| = {err:.2e}")
+    save("text_encoder", feats=feats, out=ref, surface=np.array(surface(m)))
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"small"}
     dd, oh, un, unet_ccdm, nn_ccdm = import_ccdm()
@@ -595,6 +609,8 @@ if __name__ == "__main__":
         print("unets"); fx_unets(un, ldm)
         print("chains"); fx_chains(dd, oh, un, ldm)
         print("surfaces"); fx_full_surfaces(un, ldm)
+    if "text" in which or "small" in which or "all" in which:
+        print("text encoder"); fx_text_encoder()
     if "glue" in which or "small" in which or "all" in which:
         print("glue"); fx_glue()
     if "c1" in which or "all" in which:

@@ -408,3 +408,31 @@ def test_checkpoint_importers_ignite_and_lightning(dev, tmp_path):
     live_run = sample_diffusion.sample_cond(_small_ldm(dev, use_ema=False, prefix="ckpt."), {"wholemask": (lab.float() / 255.0)[None, ..., None]},
                                             n_samples=1, ddim_steps=5, noise_seed=11)
     assert not torch.allclose(live_run[0, 0], want[0, 0], atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ text conditioning (8f-4)
+def test_text_encoder_full_size_vs_reference_fixture_and_crossattn_unet(dev):
+    """PreloadedBERTEncoder at its shipped size (768, 8 x 64, depth 4) vs the REFERENCE's output (text_encoder.npz), then the
+    whole text path on a small LDM UNet: cached features -> encoder -> context -> SpatialTransformer cross-attention, vs the
+    oracle chain (both halves of which are pinned by reference fixtures)."""
+    from jointimagegeneration_amd.encoder import PreloadedBERTEncoder
+    from jointimagegeneration_amd.unet import UNetModel
+    g = gold("text_encoder")
+    enc = seeded(PreloadedBERTEncoder(embed_dim=768, n_heads=8, depth=4, d_head=64, dropout=0.1), "bertenc.").to(dev)
+    out = enc(T(g["feats"]).to(dev))
+    e_max, e_rms = rel_err(out, T(g["out"])), rms_err(out, T(g["out"]))
+    print(f"text encoder 768 x 40 tokens, depth 4: max {e_max:.3e} rms {e_rms:.3e} vs the reference")
+    assert e_max < 3e-2 and e_rms < 1e-2
+    # small chain: encoder (64-d features, 9 tokens) -> context [b, l, c] -> UNet with SpatialTransformer
+    enc2 = seeded(PreloadedBERTEncoder(embed_dim=64, n_heads=2, depth=2, d_head=32, dropout=0.0), "bertenc_small.")
+    unet = seeded(UNetModel(**dict(LDM_SMALL, use_spatial_transformer=True, context_dim=64, transformer_depth=1)), "ldm_txt.")
+    ge = gen(5)
+    feats = torch.randn(2, 64, 9, generator=ge)
+    x, t = torch.randn(2, 8, 16, 16, generator=ge), torch.tensor([981, 981])
+    ref_ctx = O.preloaded_bert_encoder(sd_cpu(enc2), feats, 2).permute(0, 2, 1)
+    ref = O.unet_forward(sd_cpu(unet), x, t, model_channels=32, head_channels=32, context=ref_ctx)
+    ctx = enc2.to(dev)(feats.to(dev)).permute(0, 2, 1).contiguous()
+    assert rel_err(ctx, ref_ctx) < 3e-2
+    got = unet.to(dev)(x.to(dev), t.to(dev), context=ctx)
+    print(f"text path (encoder -> cross-attention UNet): max {rel_err(got, ref):.3e} rms {rms_err(got, ref):.3e}")
+    assert rel_err(got, ref) < 6e-2 and rms_err(got, ref) < 3e-2          # two bf16 networks in series (measured 2.4e-2 / 2.0e-2)

@@ -263,3 +263,20 @@ def test_product_host_zoom_index_equals_oracle():
     g = gold("glue")
     for n_in, n_out in g["pairs"]:
         assert np.array_equal(ops.zoom0_index(int(n_in), int(n_out)).numpy(), g[f"idx_{int(n_in)}_{int(n_out)}"])
+
+
+def test_text_encoder_oracle_and_surface_match_reference_fixture():
+    """PreloadedBERTEncoder.  Oracle == the reference's output (fixture made by the imported reference), and the
+    product module exposes the reference's state_dict names and shapes."""
+    import json
+    from jointimagegeneration_amd.encoder import PreloadedBERTEncoder, build_feature_cond_encoder
+    g = gold("text_encoder")
+    m = seeded(PreloadedBERTEncoder(embed_dim=768, n_heads=8, depth=4, d_head=64, dropout=0.1), "bertenc.")
+    assert surface(m) == json.loads(str(g["surface"]))
+    out = O.preloaded_bert_encoder(sd_cpu(m), T(g["feats"]), 8)
+    assert float((out - T(g["out"])).abs().max()) < 2e-5
+    built = build_feature_cond_encoder({"feature_cond_encoder": dict(type="selfattn", embed_dim=64, n_heads=2, model_depth=1, d_head=32, dropout=0.0)})
+    assert isinstance(built, PreloadedBERTEncoder) and len(built.transformer_blocks) == 1
+    assert build_feature_cond_encoder({"feature_cond_encoder": dict(type="none")}) is None
+    with pytest.raises(NotImplementedError):
+        build_feature_cond_encoder({"feature_cond_encoder": dict(type="dino", model="dino_vits8")})
