@@ -60,19 +60,8 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
     const int ih0 = UP ? h0 / 2 - 1 : h0 - 1;
     const int iw0 = UP ? w0 / 2 - 1 : w0 - 1;
 
-    // ---- per-thread staging duties (piece = 16 B = 8 channels; q is the same for all of a thread's pieces).
-    // The source position of piece j is recomputed per chunk (constexpr divisors: a few VALU) instead of pinning JMAX VGPRs.
+    // ---- per-thread staging duties: piece = 16 B = 8 channels; the channel piece xq is the same for all of a thread's pieces
     const int xq = tid & 3;
-    auto src_pos = [&](int j) -> int {            // position index of the piece's row in the source tensor, -1 = zero padding
-        const int i = tid + NTHR * j;
-        if (i >= NPIECE) return -1;
-        const int row = i >> 2;
-        const int hd = row / (HH * HW), rem = row - hd * (HH * HW);
-        const int hh = rem / HW, hw = rem - hh * HW;
-        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-        if (id < 0 || id >= p.D || ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) return -1;
-        return ((n * p.D + id) * p.H + ih) * p.W + iw;
-    };
 
     // ---- per-lane activation-operand row offsets: row(tap) = RD(tile,kd) + RH(tile,kh) + rw[kw]; only rw depends on the lane
     int rw[3];
@@ -126,20 +115,42 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
                 b0 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so); b1 = *reinterpret_cast<const f32x4 *>(p.gn_shift + so + 4);
             }
             constexpr int JG = 3;                                   // pieces in flight per thread (bounds the VGPR footprint)
+            // The piece of step j is box row (tid >> 2) + (NTHR / 4) j: its (hd, hh, hw) is decoded once per chunk and then stepped
+            // with carries (no integer division per piece: the staging phase is VALU-bound, in-kernel stamps in DESIGN.md 5.2);
+            // padding rows load from a clamped address and are zeroed by a select, so the loads of a round issue back to back.
+            constexpr int RSTEP = NTHR / 4;
+            constexpr int SD = RSTEP / (HH * HW), SREM = RSTEP % (HH * HW), SH = SREM / HW, SW = SREM % HW;
+            int chd, chh, chw;
+            {
+                const int row0 = tid >> 2;
+                chd = row0 / (HH * HW);
+                const int rem = row0 - chd * (HH * HW);
+                chh = rem / HW;
+                chw = rem - chh * HW;
+            }
+            int crow = tid >> 2;
+            const bf16_t *srcn = src + (long long)n * p.D * p.H * p.W * Cs + coff;
 #pragma unroll 1
             for (int j0 = 0; j0 < JMAX; j0 += JG) {
                 u32x4 v[JG];
                 bool ok[JG];
+                int lrow[JG], lsw[JG];
 #pragma unroll
                 for (int jj = 0; jj < JG; ++jj) {
-                    v[jj] = u32x4{0u, 0u, 0u, 0u};
-                    const int sp = src_pos(j0 + jj);
-                    ok[jj] = sp >= 0;
-                    if (ok[jj]) v[jj] = *reinterpret_cast<const u32x4 *>(src + (long long)sp * Cs + coff);
+                    const int id = id0 + chd, ih = ih0 + chh, iw = iw0 + chw;
+                    ok[jj] = crow < NROWS && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    const unsigned pos = ok[jj] ? (unsigned)((id * p.H + ih) * p.W + iw) : 0u;
+                    v[jj] = *reinterpret_cast<const u32x4 *>(srcn + pos * (unsigned)Cs);
+                    lrow[jj] = crow;
+                    lsw[jj] = fsw(chw);
+                    crow += RSTEP;
+                    chw += SW; chh += SH; chd += SD;
+                    if (chw >= HW) { chw -= HW; chh += 1; }
+                    if (chh >= HH) { chh -= HH; chd += 1; }
                 }
 #pragma unroll
                 for (int jj = 0; jj < JG; ++jj) {
-                    if (p.prologue_act && ok[jj]) {
+                    if (p.prologue_act) {
                         bf16x8 xb = __builtin_bit_cast(bf16x8, v[jj]);
                         bf16x8 yb;
 #pragma unroll
@@ -154,11 +165,9 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
                         }
                         v[jj] = __builtin_bit_cast(u32x4, yb);
                     }
-                    const int i = tid + NTHR * (j0 + jj);
-                    if (i < NPIECE) {
-                        const int row = i >> 2;
-                        *reinterpret_cast<u32x4 *>(xs + row * 64 + (xq ^ fsw(row % HW)) * 16) = v[jj];
-                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[jj][e] = ok[jj] ? v[jj][e] : 0u;          // zero padding stays zero
+                    if (lrow[jj] < NROWS) *reinterpret_cast<u32x4 *>(xs + lrow[jj] * 64 + (xq ^ lsw[jj]) * 16) = v[jj];
                 }
             }
         }
