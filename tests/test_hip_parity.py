@@ -2,7 +2,8 @@
 
 Tolerances (stated, not tuned per case): the engine stores activations/weights in bf16 and accumulates in fp32, the
 oracle is fp32 end to end, so single ops are held to 2e-2 of the reference's max magnitude (1e-2 when the oracle is fed
-bf16-rounded operands), whole networks to 6e-2 (rms 2e-2); integer outputs (labels) must be bit-exact whenever the
+bf16-rounded operands), whole small networks to 3-4e-2 (rms 2e-2), few-step chains to 2-3e-2: 2-3x the measured errors
+(tools/measure_small_net_errors.py prints them); integer outputs (labels) must be bit-exact whenever the
 kernel is fed the same fp32 probabilities as the oracle.
 """
 import json
@@ -678,16 +679,16 @@ def test_small_networks_match_reference_fixtures(dev, hint, monkeypatch):
     lab = T(g["ccdm_labels"]).long()
     out = u(S.one_hot_bchw(lab, K).to(dev), torch.zeros(1, 1, 8, 8, 8, device=dev), None, T(g["ccdm_t"]).to(dev))["diffusion_out"]
     assert out.shape == (1, K, 8, 8, 8)
-    assert float((out.cpu() - T(g["ccdm_probs"])).abs().max()) < 2e-2            # probabilities: absolute tolerance
+    assert float((out.cpu() - T(g["ccdm_probs"])).abs().max()) < 1.5e-2          # probabilities: absolute tolerance (measured 6.3e-3)
     assert torch.allclose(out.sum(1).cpu(), torch.ones(1, 8, 8, 8), atol=1e-5)
     e = u2(T(g["ldm_x"]).to(dev), T(g["ldm_t"]).to(dev))
-    assert rel_err(e, T(g["ldm_eps"])) < 6e-2 and rms_err(e, T(g["ldm_eps"])) < 2e-2
+    assert rel_err(e, T(g["ldm_eps"])) < 3e-2 and rms_err(e, T(g["ldm_eps"])) < 2e-2          # measured 9.5e-3 / 9.8e-3
     e = u3(T(g["ldm_x"]).to(dev), T(g["ldm_t"]).to(dev), context=T(g["ldmst_ctx"]).to(dev))
-    assert rel_err(e, T(g["ldmst_eps"])) < 6e-2 and rms_err(e, T(g["ldmst_eps"])) < 2e-2
+    assert rel_err(e, T(g["ldmst_eps"])) < 4e-2 and rms_err(e, T(g["ldmst_eps"])) < 2.5e-2    # measured 1.3e-2 / 1.4e-2
     dec = ae.decode(T(g["ae_z"]).to(dev))
-    assert rel_err(dec, T(g["ae_dec"])) < 6e-2 and rms_err(dec, T(g["ae_dec"])) < 2e-2
+    assert rel_err(dec, T(g["ae_dec"])) < 4e-2 and rms_err(dec, T(g["ae_dec"])) < 2e-2        # measured 1.3e-2 / 1.1e-2
     mode = ae.encode(T(g["ae_img"]).to(dev)).mode()
-    assert rel_err(mode, T(g["ae_mode"])) < 6e-2 and rms_err(mode, T(g["ae_mode"])) < 2e-2
+    assert rel_err(mode, T(g["ae_mode"])) < 4e-2 and rms_err(mode, T(g["ae_mode"])) < 2e-2    # measured 1.7e-2 / 1.1e-2
 
 
 # ------------------------------------------------------------------------------------------------ chains
@@ -742,17 +743,17 @@ def test_ldm_pipeline_ddim_chain(dev):
                                linear_end=0.0195, timesteps=1000, image_size=8, channels=4, dims=2, first_stage_key="image",
                                cond_stage_key="mask", num_timesteps_cond=1), "ldm_pipe.").to(dev)
     c = m.get_learned_conditioning(T(g["ldm_concat_cond"]).to(dev))
-    assert rel_err(c, T(g["ldm_c"])) < 6e-2
+    assert rel_err(c, T(g["ldm_c"])) < 3e-2                                          # measured 1.3e-2
     sampler = DDIMSampler(m)
     z, _ = sampler.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2,
                           noise_tape=list(T(g["ldm_noises"])))
-    assert rel_err(z, T(g["ldm_z"])) < 8e-2 and rms_err(z, T(g["ldm_z"])) < 3e-2
+    assert rel_err(z, T(g["ldm_z"])) < 2e-2 and rms_err(z, T(g["ldm_z"])) < 1.5e-2           # measured 6.6e-3 / 5.4e-3
     dec = m.decode_first_stage(z)
-    assert rel_err(dec, T(g["ldm_dec"])) < 1e-1 and rms_err(dec, T(g["ldm_dec"])) < 4e-2
+    assert rel_err(dec, T(g["ldm_dec"])) < 3e-2 and rms_err(dec, T(g["ldm_dec"])) < 2.5e-2     # measured 9.6e-3 / 1.2e-2
     # PLMS sampler on the same engine (plms.py:118-236): Euler start + Adams-Bashforth 2..4
     from jointimagegeneration_amd.ldm import PLMSSampler
     zp, _ = PLMSSampler(m).sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev))
-    assert rel_err(zp, T(g["ldm_plms_z"])) < 1e-1 and rms_err(zp, T(g["ldm_plms_z"])) < 4e-2
+    assert rel_err(zp, T(g["ldm_plms_z"])) < 1.5e-2 and rms_err(zp, T(g["ldm_plms_z"])) < 1e-2   # measured 4.3e-3 / 3.6e-3
     with pytest.raises(ValueError, match="must be 0 for PLMS"):
         PLMSSampler(m).sample(S=10, batch_size=2, shape=(4, 8, 8), conditioning=c, eta=0.5)
     # vanilla ancestral sampling (LatentDiffusion.p_sample_loop) on a 20-step schedule, same networks (same parameter names)
@@ -760,7 +761,7 @@ def test_ldm_pipeline_ddim_chain(dev):
                                  linear_end=0.0195, timesteps=20, image_size=8, channels=4, dims=2, first_stage_key="image",
                                  cond_stage_key="mask", num_timesteps_cond=1), "ldm_pipe.").to(dev)
     zv = m20.p_sample_loop(c, (2, 4, 8, 8), x_T=T(g["ldm_x_T"]).to(dev), verbose=False, noise_tape=list(T(g["ldm_vanilla_noises"])))
-    assert rel_err(zv, T(g["ldm_vanilla_z"])) < 1e-1 and rms_err(zv, T(g["ldm_vanilla_z"])) < 4e-2
+    assert rel_err(zv, T(g["ldm_vanilla_z"])) < 1.5e-2 and rms_err(zv, T(g["ldm_vanilla_z"])) < 1e-2   # measured 3.0e-3 / 3.6e-3
     # hipGraph path == eager path, bit for bit (eta = 0, no tape)
     s2 = DDIMSampler(m)
     za, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
