@@ -85,6 +85,17 @@ typedef struct {
                                   statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc (4 stripes) or gg_groupnorm_scale_shift_acc.
                                   Only filled when gg_conv_emits_stats(desc) != 0, which also gives the stripe count (4: box / 160-step
                                   kernels without split-K; 32: halo-tile kernel); bf16 output only. */
+    /* Optional fused DDIM update as the epilogue of the UNet HEAD conv (ldm/models/diffusion/ddim.py:190-204; replaces a separate
+     * gg_ddim_step launch).  Only when gg_conv_fuses_ddim(desc) == 1 (box kernel, Cout == 4 == channels of the state, fp32 output): for
+     * every output position the epilogue, besides storing eps, computes pred_x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t) and x_prev =
+     * sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) eps (sigma-noise NOT added: deterministic eta = 0 steps only) with the same
+     * fp32 expression order as gg_ddim_step, and writes x_prev over ddim_x, pred_x0 to ddim_pred_x0, bf16(x_prev) into channels [0, 4)
+     * of ddim_unet_in.  All NULL = plain conv. */
+    float *ddim_x;               /* fp32 CL [M, 4] state, updated in place                                 */
+    const float *ddim_scalars;   /* device fp32[4]: a_t, a_prev, sigma, sqrt(1 - a_t)                      */
+    float *ddim_pred_x0;         /* fp32 CL [M, 4] or NULL                                                 */
+    void *ddim_unet_in;          /* bf16 CL [M, ddim_unet_in_stride] or NULL                               */
+    int64_t ddim_unet_in_stride;
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -102,6 +113,8 @@ int gg_conv_fuses_prologue(const gg_conv_desc *desc);
 /* 0 if gg_conv_forward(desc) will not fill desc->gn_acc, else the number of stripes S of the [N][S][Cout_pad][2] accumulator it fills
  * (4 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
 int gg_conv_emits_stats(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) can run the fused DDIM epilogue (see gg_conv_desc.ddim_x); pointers are not read. */
+int gg_conv_fuses_ddim(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -16,6 +16,10 @@ struct ConvParams {
     float *ws;                // split-K slabs [splitk][M][Cout_pad] fp32 (splitk > 1)
     int splitk;
     long long *gn_acc;        // per-channel fixed-point (sum, sumsq) accumulators of the outputs [N][Cout_pad][2], or nullptr
+    float *ddim_x, *ddim_pred_x0;      // fused DDIM epilogue of the UNet head conv (gg_conv_desc.ddim_x), box kernel only
+    const float *ddim_scalars;
+    bf16_t *ddim_unet_in;
+    long long ddim_unet_in_stride;
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

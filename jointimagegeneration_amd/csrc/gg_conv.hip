@@ -640,6 +640,8 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.ws = nullptr;
     p.splitk = 1;
     p.gn_acc = (long long *)d->gn_acc;
+    p.ddim_x = d->ddim_x; p.ddim_pred_x0 = d->ddim_pred_x0; p.ddim_scalars = d->ddim_scalars;
+    p.ddim_unet_in = (bf16_t *)d->ddim_unet_in; p.ddim_unet_in_stride = d->ddim_unet_in_stride;
 }
 
 static bool halo_try_dry(const ConvParams &p) { return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK; }
@@ -657,6 +659,17 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 }
 
 bool gg_conv_box_emits_stats(const ConvParams &p);
+
+// The fused DDIM epilogue lives in the box kernel's epilogue (the latent UNet's head conv at batch 1..4 runs there).
+extern "C" int gg_conv_fuses_ddim(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->out_dtype != GG_F32 || d->Cout != 4 || d->residual) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    if (halo_try_dry(p)) return 0;
+    return gg_conv_box_try(p, (hipStream_t)-1) == GG_OK ? 1 : 0;
+}
+
 
 // Which path a desc takes is decided by the same plan functions gg_conv_forward uses.
 extern "C" int gg_conv_emits_stats(const gg_conv_desc *d)
@@ -697,6 +710,8 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
         GG_FAIL(GG_ERR_BAD_SHAPE, "conv: output extent (%d,%d,%d) inconsistent with input (%d,%d,%d) k=(%d,%d,%d) stride %d pad %d up %d",
                 d->Do, d->Ho, d->Wo, d->D, d->H, d->W, d->kd, d->kh, d->kw, d->stride, d->pad, d->upsample);
 
+    if (d->ddim_x && !gg_conv_fuses_ddim(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot run the fused DDIM epilogue (gg_conv_fuses_ddim)");
+    if (d->ddim_x && (!d->ddim_scalars || (d->ddim_unet_in && d->ddim_unet_in_stride < 4))) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: fused DDIM epilogue needs scalars / a unet_in stride >= 4");
     ConvParams p;
     fill_params(d, p);
     if (p.M >= (1LL << 31) || (long long)d->D * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1LL << 31))

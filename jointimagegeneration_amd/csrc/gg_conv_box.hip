@@ -267,6 +267,25 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
             if (co_thr + j >= p.Cout) a[j] = 0.f;
         if (p.out_dtype == GG_F32) {
             *reinterpret_cast<f32x4 *>((float *)p.out + o) = a;
+            if (p.ddim_x && co_thr == 0) {
+                // fused DDIM update (ddim.py:190-204), the UNet head conv's eps still in registers; same fp32 expression order as
+                // ddim_step_kernel (bit-identical results)
+#pragma clang fp contract(off)
+                const float a_t = p.ddim_scalars[0], a_prev = p.ddim_scalars[1], sigma = p.ddim_scalars[2], s1m = p.ddim_scalars[3];
+                const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dirc = sqrtf(1.0f - a_prev - sigma * sigma);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(p.ddim_x + mo * 4);
+                f32x4 px0, xn;
+                bf16x4 xb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    px0[j] = (xv[j] - s1m * a[j]) / sqrt_at;
+                    xn[j] = sqrt_ap * px0[j] + dirc * a[j];
+                    xb[j] = (bf16_t)xn[j];
+                }
+                *reinterpret_cast<f32x4 *>(p.ddim_x + mo * 4) = xn;
+                if (p.ddim_pred_x0) *reinterpret_cast<f32x4 *>(p.ddim_pred_x0 + mo * 4) = px0;
+                if (p.ddim_unet_in) *reinterpret_cast<bf16x4 *>(p.ddim_unet_in + mo * p.ddim_unet_in_stride) = xb;
+            }
         } else {
             bf16x4 ob;
 #pragma unroll

@@ -466,6 +466,8 @@ class DDIMSampler(object):
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.use_graph = True
+        self.fuse_ddim = True            # DDIM update as the UNet head conv's epilogue (deterministic steps)
+        self.last_step_fused = False
         self._graphs: Dict[Any, Any] = {}
 
     def register_buffer(self, name, attr):
@@ -579,9 +581,14 @@ class DDIMSampler(object):
         M = st["x"].numel() // Cx
 
         def step(noise):
-            unet.forward_cl(xin, st["cur_bias"], ctx_cl, head_out=st["eps"])
-            ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), st["cur_scal"], noise=noise,
-                          pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
+            # deterministic steps: the update is the head conv's epilogue where the kernel supports it (Cx == 4 on the box kernel)
+            hd = (st["x"].view(M, Cx), st["cur_scal"], st["pred_x0"].view(M, Cx), st["unet_in"].view(M, -1)) \
+                if (noise is None and self.fuse_ddim and Cx == 4) else None
+            head = unet.forward_cl(xin, st["cur_bias"], ctx_cl, head_out=st["eps"], head_ddim=hd)
+            self.last_step_fused = head.fused_ddim
+            if not head.fused_ddim:
+                ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), st["cur_scal"], noise=noise,
+                              pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
 
         need_noise = eta != 0.0 or noise_tape is not None
         graphable = self.use_graph and not need_noise and ctx_cl is None and S > 2

@@ -73,6 +73,7 @@ class CL:
     t: torch.Tensor
     C: int
     acc: Optional[torch.Tensor] = None      # int64 [N, stripes, Cpad, 2]: striped fixed-point per-channel (sum, sumsq) left by the producing conv
+    fused_ddim: bool = False                # the producing (head) conv already applied the DDIM update (gg_conv_desc.ddim_x)
 
     @property
     def N(self): return self.t.shape[0]
@@ -212,7 +213,9 @@ def _stats_alloc(device, N: int, cp: int, stripes: int) -> Optional[torch.Tensor
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
-         out: Optional[torch.Tensor] = None) -> CL:
+         out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None) -> CL:
+    """ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
+    runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step."""
     lib = _lib.load()
     t1 = src1.t
     N, D, H, W, C1 = t1.shape
@@ -252,8 +255,16 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
             acc = _stats_alloc(t1.device, N, cp, stripes)
             if acc is not None:
                 d.gn_acc = acc.data_ptr()
+    fused = False
+    if ddim is not None and lib.gg_conv_fuses_ddim(C.byref(d)):
+        x, scal, px0, uin = ddim
+        d.ddim_x, d.ddim_scalars = x.data_ptr(), scal.data_ptr()
+        d.ddim_pred_x0 = _ptr(px0)
+        d.ddim_unet_in = _ptr(uin)
+        d.ddim_unet_in_stride = uin.shape[-1] if uin is not None else 0
+        fused = True
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
-    return CL(out, cout, acc)
+    return CL(out, cout, acc=acc, fused_ddim=fused)
 
 
 # ----------------------------------------------------------------------------------------------- norms / elementwise

@@ -70,6 +70,7 @@ def test_c2_full_ldm_unet_50_ddim_steps_vs_reference_fixture(dev):
         e_max, e_rms = rel_err(z, ref), rms_err(z, ref)
         print(f"C2 (graph={use_graph}): 50-step DDIM latent vs reference: max {e_max:.3e} of max|z|, rms {e_rms:.3e}")
         assert e_rms < 1e-2 and e_max < 2e-2
+        assert s.last_step_fused                     # the DDIM update ran as the head conv's epilogue (no separate launch)
         if use_graph:
             zg = z
     assert torch.equal(zg, z)                        # captured hipGraph == eager launches, bit for bit
@@ -194,7 +195,9 @@ def test_c4_full_slice_512_cond_encode_ddim_decode_vs_oracle(dev):
     c = m.get_learned_conditioning(concat_cond.to(dev))
     print(f"C4 cond-encode @512^2: max {rel_err(c, ref_c):.3e}, rms {rms_err(c, ref_c):.3e}")
     assert rel_err(c, ref_c) < 6e-2 and rms_err(c, ref_c) < 2e-2
-    z, _ = DDIMSampler(m).sample(S=50, batch_size=1, shape=(4, 64, 64), conditioning=c, verbose=False, x_T=x_T.to(dev), dims=2, eta=0.0)
+    smp = DDIMSampler(m)
+    z, _ = smp.sample(S=50, batch_size=1, shape=(4, 64, 64), conditioning=c, verbose=False, x_T=x_T.to(dev), dims=2, eta=0.0)
+    assert smp.last_step_fused                       # C4 / C5 shape: DDIM update fused into the head conv
 
     def eps(x, t):
         return O.unet_forward(sd_unet, torch.cat([x, ref_c], 1), t, model_channels=160, head_channels=32)

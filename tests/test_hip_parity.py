@@ -770,6 +770,13 @@ def test_ldm_pipeline_ddim_chain(dev):
     assert torch.equal(za, zb)
     zc, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
     assert torch.equal(za, zc)          # replaying the cached graph on fresh inputs
+    # DDIM update as the head conv's epilogue == the separate gg_ddim_step launch, bit for bit (latent AND pred_x0)
+    s4 = DDIMSampler(m); s4.fuse_ddim = False
+    zd, inter_d = s4.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
+    s5 = DDIMSampler(m)
+    ze, inter_e = s5.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
+    assert s4.last_step_fused is False and torch.equal(zd, ze) and torch.equal(inter_d["pred_x0"][1], inter_e["pred_x0"][1])
+    assert torch.equal(zd, za)
 
 
 # ------------------------------------------------------------------------------------------------ glue + entry points
