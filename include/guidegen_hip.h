@@ -65,7 +65,9 @@ typedef struct {
                                   0 none, 1: silu(x*gn_scale + gn_shift), 2: x*gn_scale + gn_shift        */
     int32_t path_hint;         /* 0 = production dispatch.  1 (tests only) = take the halo-tile kernel whenever the shape is inside
                                   its envelope, even when the grid would under-fill the chip (the production gate then prefers
-                                  the box / split-K kernels): lets small test shapes exercise the kernel the big shapes use */
+                                  the box / split-K kernels): lets small test shapes exercise the kernel the big shapes use, with its
+                                  512-position box.  4 (tests only) = the same with the 256-position box the production dispatch
+                                  picks for 3-D grids of <= 256 workgroups */
     const void *src1;          /* bf16 CL [N,D,H,W,C1]                                                   */
     const void *src2;          /* bf16 CL [N,D,H,W,C2] or NULL                                           */
     const void *weight;        /* packed by gg_conv_pack_weight                                          */

@@ -1,7 +1,8 @@
 // Halo-tile implicit-GEMM convolution for gfx950: 3x3(x3), stride 1, pad 1 (optionally with the nearest x2 upsample
 // fused in front), bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
 //
-// One workgroup (8 waves) owns an output box of 512 positions (3-D: 4x8x16, 2-D: 1x32x16) x BN = 32*NT output channels.
+// One workgroup owns an output box of 512 positions (3-D: 4x8x16, 2-D: 1x32x16; HB: 256 positions, 4x4x16) x BN = 32*NT output
+// channels.
 // Per 32-channel chunk of the input:
 //   1. the INPUT box that the 27 (9) taps touch (3-D: 6x10x18 rows, 2-D: 34x18; upsample: 4x6x10 / 18x10) is staged ONCE into
 //      LDS as 64-byte rows (zero padding, two-source concat, and GroupNorm*SiLU applied here, once per element);
@@ -15,14 +16,14 @@
 #define GG_HALO_WPS(NT) 2      /* measured: 4 waves/SIMD forces scratch spills (NT=2) and is not faster */
 #endif
 
-template <int D3, int NT, int UP>
-__global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+template <int D3, int NT, int UP, int HB>
+__global__ __launch_bounds__((NT <= 2 ? 256 : 512), (HB ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? (HB ? 4 : 8) : 32, TW = 16;
     // NT <= 2: 4 waves x 8 position-tiles (128 pos x 32*NT couts per wave, 2 workgroups per CU overlap staging and MFMA);
     // NT >= 3: 8 waves x 4 position-tiles (the accumulator would not fit otherwise)
     constexpr int NWAVE = NT <= 2 ? 4 : 8;
-    constexpr int TPW = 32 / NWAVE;
+    constexpr int TPW = (TD * TH) / NWAVE;
     constexpr int NTHR = NWAVE * 64;
     constexpr int KD = D3 ? 3 : 1;
     constexpr int NTAPS = KD * 9;
@@ -282,13 +283,13 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void conv_halo_kernel(con
     }
 }
 
-template <int D3, int NT, int UP>
+template <int D3, int NT, int UP, int HB = 0>
 static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? 8 : 32, TW = 16;
+    constexpr int TD = D3 ? 4 : 1, TH = D3 ? (HB ? 4 : 8) : 32, TW = 16;
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP>), grid, dim3(NT <= 2 ? 256 : 512), 0, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3(NT <= 2 ? 256 : 512), 0, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -331,10 +332,18 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (!NT) NT = 1;
     const long long blocks = tiles * (G / NT);
     // under-filled grids: the box / split-K gather paths are faster (2-D under one workgroup per CU: AE 512->512 @64x64 is 136 us
-    // here at 128 workgroups); path_hint 1 (tests) lifts the gate so that small shapes run on this kernel
+    // here at 128 workgroups); path_hint 1 / 4 (tests) lift the gate so that small shapes run on this kernel
     const long long min_blocks = (d3 || (wide2d && NT > 1)) ? 128 : 256;
-    if (p.path_hint != 1 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
+    if (p.path_hint == 0 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
+    // 3-D grids of at most one 512-position workgroup per CU: 256-position boxes (HB: 4x4x16, three workgroups per CU) double the
+    // grid; same-box A/B 256->256 @32^3: 141 vs 156 us.  On filled grids the two box sizes are within +-3 % (64->64 @128^3
+    // 525-534 vs 519-571 us, 192->64 1464-1467 vs 1370-1442 us), so those keep the box with the smaller halo.
+    // path_hint (tests): 1 = always the 512-position box, 4 = the 256-position box wherever it is instantiated (NT <= 2).
+    if (d3 && NT <= 2 && (p.path_hint == 4 || (p.path_hint == 0 && blocks <= 256))) {
+        if (NT == 2) return p.upsample ? launch_halo<1, 2, 1, 1>(p, stream) : launch_halo<1, 2, 0, 1>(p, stream);
+        return p.upsample ? launch_halo<1, 1, 1, 1>(p, stream) : launch_halo<1, 1, 0, 1>(p, stream);
+    }
     if (d3) return p.upsample ? dispatch_nt<1, 1>(p, NT, stream) : dispatch_nt<1, 0>(p, NT, stream);
     return p.upsample ? dispatch_nt<0, 1>(p, NT, stream) : dispatch_nt<0, 0>(p, NT, stream);
 }

@@ -12,11 +12,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture
-def halo_hint(monkeypatch):
-    """Run small shapes on the halo-tile conv kernel (gg_conv_desc.path_hint = 1 lifts its >= 128-workgroup production gate);
-    every test WITHOUT this fixture runs under the production dispatch."""
+@pytest.fixture(params=[1, 4], ids=["box512", "box256"])
+def halo_hint(monkeypatch, request):
+    """Run small shapes on the halo-tile conv kernel (gg_conv_desc.path_hint = 1 / 4 lifts its >= 128-workgroup production gate;
+    1: 512-position boxes, 4: the 256-position 3-D boxes of under-filled grids); every test WITHOUT this fixture runs under the
+    production dispatch."""
     from jointimagegeneration_amd import ops
-    monkeypatch.setattr(ops, "PATH_HINT", 1)
+    monkeypatch.setattr(ops, "PATH_HINT", request.param)
     yield
 
