@@ -560,8 +560,7 @@ class DDIMSampler(object):
                   pred_x0=torch.empty((N,) + sp3 + (Cx,), dtype=torch.float32, device=dev),
                   unet_in=torch.zeros((N,) + sp3 + (pad32(Cx + Cc),), dtype=torch.bfloat16, device=dev),
                   eps=torch.empty((N,) + sp3 + (pad32(unet.out_channels),), dtype=torch.float32, device=dev),
-                  cur_scal=torch.empty(4, dtype=torch.float32, device=dev), graph=None, warmed=False)
-        st["cur_bias"] = torch.empty_like(st["table"][0])
+                  graph=None, warmed=False)
         self._graphs[key] = st
         return st
 
@@ -574,42 +573,50 @@ class DDIMSampler(object):
         if c_concat is not None:
             ops.to_cl(c_concat.float(), out=st["unet_in"], c_offset=st["Cx"], zero_fill=False)
 
-    def run_steps(self, st, ctx_cl, eta, noise_tape):
+    def _step(self, st, ctx_cl, bias, scal, noise):
+        """One reverse step on the state's buffers; `bias` / `scal` are rows of the per-schedule tables (ddim.py:165-205)."""
         unet = self.model.model.diffusion_model
-        N, Cx, Cc, S = st["N"], st["Cx"], st["Cc"], st["S"]
-        xin = CL(st["unet_in"], Cx + Cc)
+        Cx, Cc = st["Cx"], st["Cc"]
         M = st["x"].numel() // Cx
+        # deterministic steps: the update is the head conv's epilogue where the kernel supports it (Cx == 4 on the box kernel)
+        hd = (st["x"].view(M, Cx), scal, st["pred_x0"].view(M, Cx), st["unet_in"].view(M, -1)) \
+            if (noise is None and self.fuse_ddim and Cx == 4) else None
+        head = unet.forward_cl(CL(st["unet_in"], Cx + Cc), bias, ctx_cl, head_out=st["eps"], head_ddim=hd)
+        self.last_step_fused = head.fused_ddim
+        if not head.fused_ddim:
+            ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), scal, noise=noise,
+                          pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
 
-        def step(noise):
-            # deterministic steps: the update is the head conv's epilogue where the kernel supports it (Cx == 4 on the box kernel)
-            hd = (st["x"].view(M, Cx), st["cur_scal"], st["pred_x0"].view(M, Cx), st["unet_in"].view(M, -1)) \
-                if (noise is None and self.fuse_ddim and Cx == 4) else None
-            head = unet.forward_cl(xin, st["cur_bias"], ctx_cl, head_out=st["eps"], head_ddim=hd)
-            self.last_step_fused = head.fused_ddim
-            if not head.fused_ddim:
-                ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), st["cur_scal"], noise=noise,
-                              pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
+    def chain_graphable(self, st, ctx_cl=None, eta=0.0, noise_tape=None) -> bool:
+        return bool(self.use_graph and eta == 0.0 and noise_tape is None and ctx_cl is None and st["S"] > 2)
 
-        need_noise = eta != 0.0 or noise_tape is not None
-        graphable = self.use_graph and not need_noise and ctx_cl is None and S > 2
+    def chain(self, st, ctx_cl=None):
+        """All S deterministic steps back to back, every step reading ITS rows of the time-bias / scalar tables in place: no
+        per-step copies, no host decisions, so the whole chain (13 k kernel nodes at S = 50) is one capturable launch sequence."""
+        for i in range(st["S"]):
+            self._step(st, ctx_cl, st["table"][i], st["scal"][i], None)
+
+    def run_steps(self, st, ctx_cl, eta, noise_tape):
+        S = st["S"]
+        if self.chain_graphable(st, ctx_cl, eta, noise_tape):
+            # first call: eager (fills the weight-repack caches); afterwards ONE hipGraph replay per chain
+            if not st["warmed"]:
+                self.chain(st)
+                st["warmed"] = True
+                return
+            if st["graph"] is None:
+                st["graph"] = ops.capture_graph(lambda: self.chain(st))
+            st["graph"].replay()
+            return
         for i in range(S):
-            st["cur_bias"].copy_(st["table"][i]); st["cur_scal"].copy_(st["scal"][i])
-            if graphable:
-                if not st["warmed"]:
-                    step(None); st["warmed"] = True
-                    continue
-                if st["graph"] is None:
-                    st["graph"] = ops.capture_graph(lambda: step(None))
-                st["graph"].replay()
-            else:
-                noise = None
-                if noise_tape is not None:
-                    nt = noise_tape[i].to(st["x"].device).float()
-                    nd = nt.ndim - 2
-                    noise = nt.permute((0,) + tuple(range(2, nd + 2)) + (1,)).contiguous()
-                elif eta != 0.0:
-                    noise = torch.randn_like(st["x"])
-                step(noise)
+            noise = None
+            if noise_tape is not None:
+                nt = noise_tape[i].to(st["x"].device).float()
+                nd = nt.ndim - 2
+                noise = nt.permute((0,) + tuple(range(2, nd + 2)) + (1,)).contiguous()
+            elif eta != 0.0:
+                noise = torch.randn_like(st["x"])
+            self._step(st, ctx_cl, st["table"][i], st["scal"][i], noise)
 
 
 class PLMSSampler(DDIMSampler):

@@ -769,7 +769,10 @@ def test_ldm_pipeline_ddim_chain(dev):
     zb, _ = s3.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
     assert torch.equal(za, zb)
     zc, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
-    assert torch.equal(za, zc)          # replaying the cached graph on fresh inputs
+    assert torch.equal(za, zc)          # first call eager, second call = one captured graph of the whole chain
+    assert next(iter(s2._graphs.values()))["graph"] is not None
+    zc2, _ = s2.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
+    assert torch.equal(za, zc2)         # replaying the cached graph on fresh inputs
     # DDIM update as the head conv's epilogue == the separate gg_ddim_step launch, bit for bit (latent AND pred_x0)
     s4 = DDIMSampler(m); s4.fuse_ddim = False
     zd, inter_d = s4.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=T(g["ldm_x_T"]).to(dev), dims=2)
