@@ -8,7 +8,11 @@ OBJS=()
 for f in gg_conv gg_conv_halo gg_conv_box gg_conv_tiny gg_norm gg_attn gg_sampler; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gg_common.h -nt $f.o ] || [ gg_conv.h -nt $f.o ] || [ ../../include/guidegen_hip.h -nt $f.o ]; then
     echo "hipcc $f.hip"
-    $HIPCC $FLAGS -c $f.hip -o $f.o &
+    EXTRA=""
+    # attention: MFMA results feed VALU softmax code directly; without this the compiler parks the score tiles in AGPRs and pays
+    # ~250 v_accvgpr moves per 256-key tile
+    if [ $f = gg_attn ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    $HIPCC $FLAGS $EXTRA -c $f.hip -o $f.o &
   fi
   OBJS+=($f.o)
 done

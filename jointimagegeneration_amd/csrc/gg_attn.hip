@@ -155,23 +155,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
                         s[gi][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[gi][kt], 0, 0, 0);
                     }
                 }
-            // ---- online softmax (fp32, base-2)
+            // ---- online softmax (fp32, base-2).  The kernel is VALU-issue bound at batch 1 (one wave per SIMD, 64 scores per lane and
+            //      tile), so the per-score work is kept to max, one FMA, one raw v_exp_f32, one add and half a pack: the scale is
+            //      applied inside the exponent's FMA (scale > 0 commutes with the max), the key mask exists only on a ragged LAST tile
+            //      (wave-uniform branch), and v_exp_f32 is used bare (arguments <= 0; results below 2^-126 may flush to zero, they are
+            //      rounded to bf16 anyway).
+            const bool ragged = key0 + (sub0 + G) * 32 > p.Tkv;
+            if (ragged) {
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = key0 + (sub0 + gi) * 32 + kt * 16 + 4 * g + r;
+                            s[gi][kt][r] = (key < p.Tkv) ? s[gi][kt][r] : -INFINITY;
+                        }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int gi = 0; gi < G; ++gi)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + (sub0 + gi) * 32 + kt * 16 + 4 * g + r;
-                        const float v = (key < p.Tkv) ? s[gi][kt][r] * p.scale_log2 : -INFINITY;
-                        s[gi][kt][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[gi][kt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);
+            const float m_new = fmaxf(m_run, mx * p.scale_log2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float rs = 0.f;
             bf16x8 pf[G];
 #pragma unroll
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = exp2f(s[gi][kt][r] - m_new);
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[gi][kt][r], p.scale_log2, -m_new));
                         rs += pv;
                         pf[gi][kt * 4 + r] = (bf16_t)pv;
                     }
