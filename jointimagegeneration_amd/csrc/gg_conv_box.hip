@@ -43,6 +43,17 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     constexpr int NROWS = HH * HW;
     constexpr int NRB = (NROWS + 15) / 16;            // 1 KiB DMA blocks (16 rows) per chunk plane
     constexpr int PLANE = NRB * 1024;                 // one 32-channel chunk of the box
+    // Box image swizzle (16-byte chunk ^ sw).  3x3 boxes use a function of the position INSIDE a W-line only (exhaustive search
+    // over the ds_read_b128 lane groups for the three kw taps: TWI 16 -> hw in {4,5,10..15}, upsample {6..9}; TWI 8 -> {2,3,6,7};
+    // TWI 4 -> {2,3}): unlike the row-based map it is invariant under whole-line shifts (kh, the position tile), so an operand
+    // address is a per-lane constant + a wave-uniform term + an immediate.  The row-based map cost 5 VALU per operand read,
+    // 60 per k-step at 12 position tiles, MORE issue cycles than the k-step's 12 MFMAs (timing ablation: 1.76 -> 1.70 ms per
+    // latent-UNet forward).  No such map exists for the upsampled 8- / 4-wide boxes; they keep the row-based one (2 launches per
+    // forward), and so do 1x1 boxes, where the row-based map is already a lane constant.
+    constexpr bool LINE_SWZ = K3 && (TWI == 16 || !UP);
+    constexpr unsigned FMASK = TWI == 16 ? (UP ? 0x3C0u : 0xFC30u) : TWI == 8 ? 0xCCu : 0x0Cu;
+    constexpr bool LANE_ADDR = LINE_SWZ || !K3;       // operand address = lane constant + uniform + immediate
+    auto bsw = [&](int row, int hw) -> int { return LINE_SWZ ? (int)((FMASK >> hw) & 1u) << 1 : (row >> 1) & 2; };
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float *gns = reinterpret_cast<float *>(smem);     // [nch*32] scale, [nch*32] shift of the stage (fused prologue only)
     char *box = smem + gn_bytes;
@@ -86,6 +97,18 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     // staging duty of a lane inside a 16-row DMA block: row (lane>>2), LDS slot (lane&3)
     const int lrow = lane >> 2, lslot = lane & 3;
 
+    // per-lane part of the activation-operand address for the three kw taps (1x1: one)
+    int lane_off[3] = {0, 0, 0};
+    if constexpr (LINE_SWZ) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int rwk = UP ? ((pos_c + k + 1) >> 1) : (pos_c + k);
+            lane_off[k] = (UP ? 0 : pos_r * (HW * 64)) + rwk * 64 + ((fq ^ bsw(0, rwk)) * 16);
+        }
+    } else if constexpr (!K3) {
+        lane_off[0] = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
+    }
+
     for (int st = 0; st < nstage; ++st) {
         const int cbase = st * nch_stage;
         const int nch = (p.nchunk - cbase < nch_stage) ? p.nchunk - cbase : nch_stage;
@@ -115,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
             const bool second = gc >= p.nchunk1;
             const bf16_t *src = second ? p.src2 : p.src1;
             const int Cs = second ? p.C2 : p.C1;
-            const int q = lslot ^ ((row >> 1) & 2);
+            const int q = lslot ^ bsw(row, hw);
             const int coff = (second ? gc - p.nchunk1 : gc) * 32 + q * 8;
             char *dst = box + c * PLANE + rbk * 1024;
             if (row < NROWS) {
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                 const int hh = row / HW, hw = row - hh * HW;
                 const int ih = ih0 + hh, iw = iw0 + hw;
                 if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                    const int q = lslot ^ ((row >> 1) & 2);
+                    const int q = lslot ^ bsw(row, hw);
                     char *pc = box + c * PLANE + rbk * 1024 + lane * 16;
                     const float *sc = gns + c * 32 + q * 8, *sh = sc + nch * 32;
                     const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sc), sc1 = *reinterpret_cast<const f32x4 *>(sc + 4);
@@ -190,15 +213,32 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                 if (s + u < s1) {
                     const int kh = K3 ? ctap / 3 : 0, kw = K3 ? ctap - kh * 3 : 0;
                     const char *plane = box + cc * PLANE;
-                    const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
                     bf16x8 xf[MT];
+                    if constexpr (LANE_ADDR) {
+                        const int lo = K3 ? (kw == 0 ? lane_off[0] : (kw == 1 ? lane_off[1] : lane_off[2])) : lane_off[0];
+                        if constexpr (!UP) {
+                            const char *pa = plane + kh * (HW * 64) + lo;                 // one VALU add per k-step
 #pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) {
-                        const int orow = tt * RPT + pos_r;
-                        const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
-                        const int row = hh * HW + rwk;
-                        xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
+                            for (int tt = 0; tt < MT; ++tt) xf[tt] = *reinterpret_cast<const bf16x8 *>(pa + tt * (K3 ? RPT * HW * 64 : 1024));
+                        } else {                                                          // TWI == 16: line (tt + kh + 1) >> 1
+                            const char *pe = plane + ((kh + 1) >> 1) * (HW * 64) + lo, *po = plane + ((kh + 2) >> 1) * (HW * 64) + lo;
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt)
+                                xf[tt] = *reinterpret_cast<const bf16x8 *>(((tt & 1) ? po : pe) + (tt >> 1) * (HW * 64));
+                        }
+                    } else {
+                        const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt) {
+                            const int orow = tt * RPT + pos_r;
+                            const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
+                            const int row = hh * HW + rwk;
+                            xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
+                        }
                     }
+                    // all MT operand reads are issued before the first MFMA (the scheduler would otherwise pair them two by two to save
+                    // registers and expose the LDS latency once per pair); the MFMAs then drain them under counted lgkmcnt
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
