@@ -719,7 +719,13 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
 
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;
+#ifdef GG_BOX_STAMPS
+    if (d->path_hint == 98) p.ws = (float *)d->workspace;      // diagnostic build: phase stamps of the box kernel
+#endif
     rc = gg_conv_box_try(p, stream);
+#ifdef GG_BOX_STAMPS
+    p.ws = nullptr;
+#endif
     if (rc != GG_ERR_UNSUPPORTED) return rc;
 
     if (int tsk = gg_conv_tiny_plan(p.M, p.Cout_pad, p.ntaps * p.nchunk, p.prologue_act)) {

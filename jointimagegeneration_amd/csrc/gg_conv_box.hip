@@ -28,6 +28,15 @@
 #define GG_BOX_WAIT_BARRIER(VM) do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(VM)); __builtin_amdgcn_s_barrier(); } while (0)
 #define GG_BOX_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(63)); __builtin_amdgcn_s_barrier(); } while (0)
 
+// Diagnostic build only (tools/experiments/README.md): -DGG_BOX_STAMPS records s_memrealtime (100 MHz) phase stamps of waves 0 and 7
+// of every workgroup into gg_conv_desc.workspace when path_hint == 98.
+#ifdef GG_BOX_STAMPS
+#define GG_STAMP(K) do { if (p.path_hint == 98 && p.ws && lane == 0 && (wave == 0 || wave == 7)) \
+    reinterpret_cast<unsigned long long *>(p.ws)[(blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GG_STAMP(K) do { } while (0)
+#endif
+
 template <int TWI, int MT, int CT, int UP, int K3>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
                                                          const int nch_stage, const int gn_bytes, const int q_major)
@@ -62,6 +71,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int pos_r = fr / TWI, pos_c = fr % TWI;     // this lane's position inside a position tile
+    GG_STAMP(0);
 
     // ---- workgroup -> (position tile, cout tile).  Consecutive hardware ids round-robin over the 8 XCDs; give every XCD a
     //      contiguous run of virtual ids, then decode them cout-major (a run shares weights) or position-major (shares boxes).
@@ -126,29 +136,45 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                                                      (__attribute__((address_space(3))) void *)(gns + which * nch * 32 + blk * 256), 16, 0, 0);
             }
         }
-        // ---- stage the box of this stage's channels (global_load_lds, everything in flight); padding rows are zeros
+        // ---- stage the box of this stage's channels (global_load_lds, everything in flight); padding rows are zeros.
+        //      Units (16-row block rbk, chunk c) are walked block-major, each wave a contiguous eighth: everything that depends on the
+        //      block only (the lane's box row -> input position, padding, swizzle, element offsets) is set up when rbk changes, so a
+        //      unit costs ~a dozen instructions.  (Chunk-major units recomputed it per DMA: ~70 instructions, and the phase stamps
+        //      showed 4-5 us between kernel entry and the last DMA issued for a 640->640 conv at 16x16.)
         const int nunit = nch * NRB;
+        {
+            const int u0 = (nunit * wave) / NW, u1 = (nunit * (wave + 1)) / NW;
+            int rbk = u0 / nch, c = u0 - rbk * nch;
+            bool inr = false, valid = false;
+            unsigned off1 = 0u, off2 = 0u;          // byte offsets inside the sample: < 2^32 (checked on the host)
+            auto setup = [&](int rb) {
+                const int row = rb * 16 + lrow;
+                const int hh = row / HW, hw = row - hh * HW;
+                const int ih = ih0 + hh, iw = iw0 + hw;
+                inr = row < NROWS;
+                valid = inr && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const unsigned pos = valid ? (unsigned)(ih * p.W + iw) : 0u;
+                const unsigned q8 = (unsigned)((lslot ^ bsw(row, hw)) * 8);
+                off1 = (pos * (unsigned)p.C1 + q8) * 2u;
+                off2 = (pos * (unsigned)p.C2 + q8) * 2u;
+            };
+            setup(rbk);
+            const char *s1n = reinterpret_cast<const char *>(p.src1 + (long long)n * p.H * p.W * p.C1);
+            const char *s2n = reinterpret_cast<const char *>(p.src2 + (long long)n * p.H * p.W * p.C2);
 #pragma unroll 1
-        for (int unit = wave; unit < nunit; unit += NW) {
-            const int c = unit / NRB, rbk = unit - c * NRB;
-            const int row = rbk * 16 + lrow;
-            const int hh = row / HW, hw = row - hh * HW;
-            const int ih = ih0 + hh, iw = iw0 + hw;
-            const int gc = cbase + c;
-            const bool second = gc >= p.nchunk1;
-            const bf16_t *src = second ? p.src2 : p.src1;
-            const int Cs = second ? p.C2 : p.C1;
-            const int q = lslot ^ bsw(row, hw);
-            const int coff = (second ? gc - p.nchunk1 : gc) * 32 + q * 8;
-            char *dst = box + c * PLANE + rbk * 1024;
-            if (row < NROWS) {
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                    const bf16_t *sp = src + ((long long)((n * p.H + ih) * p.W + iw)) * Cs + coff;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sp,
+            for (int u = u0; u < u1; ++u) {
+                const int gc = cbase + c;
+                const bool second = gc >= p.nchunk1;
+                const char *sb = second ? s2n + (gc - p.nchunk1) * 64 : s1n + gc * 64;      // wave-uniform
+                const unsigned off = second ? off2 : off1;
+                char *dst = box + c * PLANE + rbk * 1024;
+                if (valid) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + off),
                                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                } else {
+                } else if (inr) {
                     *reinterpret_cast<u32x4 *>(dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
                 }
+                if (++c == nch) { c = 0; ++rbk; setup(rbk); }
             }
         }
         // ---- weight stream of this wave: steps s in [s0, s1), s = tap * nch + c.  Loads past the end re-read the last tile
@@ -173,7 +199,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
         // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
+        GG_STAMP(1);
         if (NTRIP * 4 * CT == 16) GG_BOX_WAIT_BARRIER(16); else GG_BOX_WAIT_BARRIER(12);
+        GG_STAMP(2);
 
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
 #pragma unroll 2
@@ -205,6 +233,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
             GG_BOX_LDS_BARRIER();
         }
 
+        GG_STAMP(3);
         // ---- this wave's k-steps: 4 per trip
         int ctap = s0 / nch, cc = s0 - ctap * nch;          // compute iterator
         auto trip = [&](const bf16x8 (&a)[4][CT], int s) {
@@ -259,7 +288,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         }
 #pragma unroll
         for (int r = 0; r < NTRIP; ++r) trip(wr[r], s + 4 * r);      // drain: nothing left to load
+        GG_STAMP(4);
         GG_BOX_WAIT_BARRIER(0);   // all waves done with the box: it may be overwritten (next stage / the reduction area)
+        GG_STAMP(5);
     }
 
     // ---- combine the 8 waves (fixed order), then bias / residual / store.  red[wave][tt][ct][lane] is lane-contiguous:
@@ -282,6 +313,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
     GG_BOX_LDS_BARRIER();
+    GG_STAMP(6);
     const bool stats = p.gn_acc && p.out_dtype != GG_F32;       // GroupNorm statistics of the NEXT norm (see gg_conv_desc.gn_acc)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -360,6 +392,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                       (unsigned long long)fx);
         }
     }
+    GG_STAMP(7);
 }
 
 struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; };

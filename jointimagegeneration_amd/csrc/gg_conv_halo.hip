@@ -334,7 +334,7 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     // under-filled grids: the box / split-K gather paths are faster (2-D under one workgroup per CU: AE 512->512 @64x64 is 136 us
     // here at 128 workgroups); path_hint 1 / 4 (tests) lift the gate so that small shapes run on this kernel
     const long long min_blocks = (d3 || (wide2d && NT > 1)) ? 128 : 256;
-    if (p.path_hint == 0 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
+    if (p.path_hint != 1 && p.path_hint != 4 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
     // 3-D grids of at most one 512-position workgroup per CU: 256-position boxes (HB: 4x4x16, three workgroups per CU) double the
     // grid; same-box A/B 256->256 @32^3: 141 vs 156 us.  On filled grids the two box sizes are within +-3 % (64->64 @128^3
