@@ -45,7 +45,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     constexpr int TW = TWI, NW = 8;
     constexpr int RPT = 16 / TWI;
     constexpr int TH = MT * RPT;                      // output rows of the workgroup
-    constexpr int NTRIP = CT == 2 ? 2 : 3;            // weight trips (4 k-steps each) kept in flight per wave
+    // Weight trips (4 k-steps each) kept in flight per wave: measured on the latent-UNet forward (same box, hipGraph replay):
+    // 1 trip 1707 us, 2 trips 1675, 3 trips (CT 1) 1694, 6 / 4 trips where the registers allow 1744.  What a CU can take in is the
+    // bound, so weight tiles requested early only delay the landing of the box, i.e. the start of the k-loop.
+    constexpr int NTRIP = 2;
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
         // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
         GG_STAMP(1);
-        if (NTRIP * 4 * CT == 16) GG_BOX_WAIT_BARRIER(16); else GG_BOX_WAIT_BARRIER(12);
+        GG_BOX_WAIT_BARRIER(NTRIP * 4 * CT);
         GG_STAMP(2);
 
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
                     }
                     // all MT operand reads are issued before the first MFMA (the scheduler would otherwise pair them two by two to save
                     // registers and expose the LDS latency once per pair); the MFMAs then drain them under counted lgkmcnt
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (MT * CT <= 12) __builtin_amdgcn_sched_barrier(0);      // (12 x 2: the 48 operand registers would spill)
 #pragma unroll
                     for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
