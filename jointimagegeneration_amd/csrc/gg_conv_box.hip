@@ -32,14 +32,14 @@
 // of every workgroup into gg_conv_desc.workspace when path_hint == 98.
 #ifdef GG_BOX_STAMPS
 #define GG_STAMP(K) do { if (p.path_hint == 98 && p.ws && lane == 0 && (wave == 0 || wave == 7)) \
-    reinterpret_cast<unsigned long long *>(p.ws)[(blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    reinterpret_cast<unsigned long long *>(p.ws)[(blockIdx.x * 2 + (wave ? 1 : 0)) * 16 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GG_STAMP(K) do { } while (0)
 #endif
 
 template <int TWI, int MT, int CT, int UP, int K3>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
-                                                         const int nch_stage, const int gn_bytes, const int q_major)
+                                                         const int nch_stage, const int gn_bytes, const int q_major, const int nblocks)
 {
     // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
     constexpr int TW = TWI, NW = 8;
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 
     // ---- workgroup -> (position tile, cout tile).  Consecutive hardware ids round-robin over the 8 XCDs; give every XCD a
     //      contiguous run of virtual ids, then decode them cout-major (a run shares weights) or position-major (shares boxes).
-    const int P = p.N * tiles_h * tiles_w, Q = gridDim.x / P;
+    const int P = p.N * tiles_h * tiles_w, Q = nblocks / P;
     int v = blockIdx.x;
-    if ((gridDim.x & 7) == 0) v = (v & 7) * (gridDim.x >> 3) + (v >> 3);
+    if ((nblocks & 7) == 0) v = (v & 7) * (nblocks >> 3) + (v >> 3);
     const int by = q_major ? v / P : v % Q;
     int t = q_major ? v - by * P : v / Q;
     const int stripe = t & (GG_ACC_STRIPES - 1);       // GroupNorm accumulator stripe of this position tile
@@ -145,41 +145,88 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         //      unit costs ~a dozen instructions.  (Chunk-major units recomputed it per DMA: ~70 instructions, and the phase stamps
         //      showed 4-5 us between kernel entry and the last DMA issued for a 640->640 conv at 16x16.)
         const int nunit = nch * NRB;
+        const int u0 = (nunit * wave) / NW, u1 = (nunit * (wave + 1)) / NW;
+        bool inr = false, valid = false;
+        unsigned off1 = 0u, off2 = 0u;          // byte offsets inside the sample: < 2^32 (checked on the host)
+        auto setup = [&](int rb) {
+            const int row = rb * 16 + lrow;
+            const int hh = row / HW, hw = row - hh * HW;
+            const int ih = ih0 + hh, iw = iw0 + hw;
+            inr = row < NROWS;
+            valid = inr && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const unsigned pos = valid ? (unsigned)(ih * p.W + iw) : 0u;
+            const unsigned q8 = (unsigned)((lslot ^ bsw(row, hw)) * 8);
+            off1 = (pos * (unsigned)p.C1 + q8) * 2u;
+            off2 = (pos * (unsigned)p.C2 + q8) * 2u;
+        };
+        const char *s1n = reinterpret_cast<const char *>(p.src1 + (long long)n * p.H * p.W * p.C1);
+        const char *s2n = reinterpret_cast<const char *>(p.src2 + (long long)n * p.H * p.W * p.C2);
+#ifdef GG_BOX_REG_STAGE
+        // Through registers: the phase stamps showed that a wave's global_load_lds instructions of scattered 64-byte rows go out one
+        // per ~250 ns (10 DMAs: 2.5 us before the last one is even issued, with 50 or with 240 workgroups on the chip), while plain
+        // 16-byte loads issue back to back and share one round trip.  A wave has at most MAXU = 16 units (128 KiB of box / 1 KiB / 8).
+        constexpr int MAXU = 16;
+        u32x4 sv[MAXU];
+        unsigned vmask = 0u;
+        const int cnt = u1 - u0;
         {
-            const int u0 = (nunit * wave) / NW, u1 = (nunit * (wave + 1)) / NW;
             int rbk = u0 / nch, c = u0 - rbk * nch;
-            bool inr = false, valid = false;
-            unsigned off1 = 0u, off2 = 0u;          // byte offsets inside the sample: < 2^32 (checked on the host)
-            auto setup = [&](int rb) {
-                const int row = rb * 16 + lrow;
-                const int hh = row / HW, hw = row - hh * HW;
-                const int ih = ih0 + hh, iw = iw0 + hw;
-                inr = row < NROWS;
-                valid = inr && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-                const unsigned pos = valid ? (unsigned)(ih * p.W + iw) : 0u;
-                const unsigned q8 = (unsigned)((lslot ^ bsw(row, hw)) * 8);
-                off1 = (pos * (unsigned)p.C1 + q8) * 2u;
-                off2 = (pos * (unsigned)p.C2 + q8) * 2u;
-            };
             setup(rbk);
-            const char *s1n = reinterpret_cast<const char *>(p.src1 + (long long)n * p.H * p.W * p.C1);
-            const char *s2n = reinterpret_cast<const char *>(p.src2 + (long long)n * p.H * p.W * p.C2);
-#pragma unroll 1
-            for (int u = u0; u < u1; ++u) {
-                const int gc = cbase + c;
-                const bool second = gc >= p.nchunk1;
-                const char *sb = second ? s2n + (gc - p.nchunk1) * 64 : s1n + gc * 64;      // wave-uniform
-                const unsigned off = second ? off2 : off1;
-                char *dst = box + c * PLANE + rbk * 1024;
-                if (valid) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + off),
-                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                } else if (inr) {
-                    *reinterpret_cast<u32x4 *>(dst + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < MAXU; ++j) {
+                sv[j] = u32x4{0u, 0u, 0u, 0u};
+                if (j < cnt) {
+                    const int gc = cbase + c;
+                    const bool second = gc >= p.nchunk1;
+                    const char *sb = second ? s2n + (gc - p.nchunk1) * 64 : s1n + gc * 64;      // wave-uniform
+                    const unsigned off = valid ? (second ? off2 : off1) : 0u;                   // padding: any legal address, zeroed below
+                    sv[j] = *reinterpret_cast<const u32x4 *>(sb + off);
+                    vmask |= valid ? (1u << j) : 0u;
+                    if (++c == nch) { c = 0; ++rbk; setup(rbk); }
                 }
-                if (++c == nch) { c = 0; ++rbk; setup(rbk); }
             }
         }
+#else
+        // DMA issue: every lane always issues (padding and past-the-box rows from a clamped, legal address; the padding slots are
+        // zeroed by their own wave after its DMAs have landed, below).  A wave issues its instructions one by one, so the instruction
+        // count per unit IS the staging time at batch 1 (stamps: 170 ns per unit with a predicated DMA / zero-store pair and the
+        // (block, chunk) bookkeeping per unit; 15 units per wave).  Hence runs: within one 16-row block and one source tensor,
+        // consecutive chunks are +64 B in global memory and +PLANE in LDS, and nothing else changes.
+        {
+            int rbk = u0 / nch, c = u0 - rbk * nch;
+            int left = u1 - u0;
+            GG_STAMP(8);
+            while (left > 0) {
+                setup(rbk);
+                int run = nch - c < left ? nch - c : left;                       // units of this block
+                left -= run;
+                int gc = cbase + c;
+                char *dst = box + c * PLANE + rbk * 1024;
+                // first source, then (two-source concat) second source
+                int n1 = p.nchunk1 - gc;
+                n1 = n1 < 0 ? 0 : (n1 > run ? run : n1);
+                const char *sb = s1n + gc * 64;
+#pragma unroll 2
+                for (int i = 0; i < n1; ++i) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + off1),
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    sb += 64;
+                    dst += PLANE;
+                }
+                sb = s2n + (gc + n1 - p.nchunk1) * 64;
+#pragma unroll 2
+                for (int i = n1; i < run; ++i) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + off2),
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    sb += 64;
+                    dst += PLANE;
+                }
+                c = 0;
+                ++rbk;
+            }
+        }
+#endif
+        GG_STAMP(1);
         // ---- weight stream of this wave: steps s in [s0, s1), s = tap * nch + c.  Loads past the end re-read the last tile
         //      (unconditional, branch-free: the vmcnt counts stay exact).  Issued AFTER the box so the box lands first.
         int ltap = s0 / nch, lc = s0 - ltap * nch, lidx = s0;          // load iterator
@@ -202,9 +249,38 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 #pragma unroll
         for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
         // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
-        GG_STAMP(1);
-        GG_BOX_WAIT_BARRIER(NTRIP * 4 * CT);
         GG_STAMP(2);
+#ifdef GG_BOX_REG_STAGE
+        {   // registers -> LDS (rows past the box and padding rows are written as zeros: their slots are never read / must be zero)
+            int rbk = u0 / nch, c = u0 - rbk * nch;
+#pragma unroll
+            for (int j = 0; j < MAXU; ++j) {
+                if (j < cnt) {
+                    u32x4 d = sv[j];
+                    const bool ok = (vmask >> j) & 1u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = ok ? d[e] : 0u;
+                    *reinterpret_cast<u32x4 *>(box + c * PLANE + rbk * 1024 + lane * 16) = d;
+                    if (++c == nch) { c = 0; ++rbk; }
+                }
+            }
+        }
+        // the GroupNorm rows (DMA, issued before the box loads) have landed with the box loads; only the weight trips are still out
+        GG_BOX_LDS_BARRIER();
+#else
+        // this wave's DMAs have landed once only its NTRIP*4*CT weight loads are outstanding; then zero ITS padding slots; then barrier
+        __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * 4 * CT));
+        if (ih0 < 0 || iw0 < 0 || ih0 + HH > p.H || iw0 + HW > p.W) {        // border workgroups only (wave-uniform)
+            int rbk = u0 / nch, c = u0 - rbk * nch;
+            setup(rbk);
+#pragma unroll 1
+            for (int u = u0; u < u1; ++u) {
+                if (inr && !valid) *reinterpret_cast<u32x4 *>(box + c * PLANE + rbk * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+                if (++c == nch) { c = 0; ++rbk; setup(rbk); }
+            }
+        }
+        GG_BOX_LDS_BARRIER();
+#endif
 
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
 #pragma unroll 2
@@ -470,7 +546,7 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     const int tiles_h = (p.Ho + MT * (16 / TWI) - 1) / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
     hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
-                       pl.nch_stage, pl.gn_bytes, pl.q_major);
+                       pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

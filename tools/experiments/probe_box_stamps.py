@@ -1,6 +1,6 @@
 """Phase stamps of conv_box2d_kernel (diagnostic build: hipcc -DGG_BOX_STAMPS of gg_conv.hip + gg_conv_box.hip linked into
 tools/experiments/ab/libS.so):  python tools/experiments/probe_box_stamps.py C1 C2 Cout HW k [prologue]
-Prints, over all workgroups, the s_memrealtime (10 ns ticks) of: entry, loads issued, box landed, (prologue done), k-loop done,
+Prints, over all workgroups, the s_memrealtime (10 ns ticks) of: entry, box DMAs issued, first weight trips issued, box landed (and prologue done), k-loop done,
 all waves done, combine visible, end -- relative to the first workgroup's entry."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -21,7 +21,7 @@ pw = ops.pack_conv_weight(w[:, :, None], C1 + C2)
 pb = ops.pad_bias(None, Cout, dev)
 out = torch.empty(1, 1, HW, HW, ops.pad32(Cout), dtype=torch.bfloat16, device=dev)
 res = torch.randn_like(out)
-ws = torch.zeros(1024 * 2 * 8, dtype=torch.int64, device=dev)
+ws = torch.zeros(1024 * 2 * 16, dtype=torch.int64, device=dev)
 sc = torch.ones(1, C1 + C2, device=dev); sh = torch.zeros(1, C1 + C2, device=dev)
 lib = _lib.load()
 d = ConvDesc()
@@ -45,13 +45,13 @@ for _ in range(3):
     _lib.check(lib.gg_conv_forward(C.byref(d), st), "conv")
     e1.record()
 torch.cuda.synchronize()
-t = ws.cpu().view(1024, 2, 8)
+t = ws.cpu().view(1024, 2, 16)
 nb = int((t[:, 0, 0] != 0).sum())
 t = t[:nb].double()
 t0 = t[:, 0, 0].min()
-names = ["entry", "loads issued", "box landed", "prologue done", "k-loop done", "all waves done", "combine visible", "end"]
+names = ["entry", "box DMAs issued", "weights issued", "box landed (+pro)", "k-loop done", "all waves done", "combine visible", "end", "before DMA loop", "1 DMA issued", "4 DMAs issued"]
 print(f"box conv {C1}+{C2}->{Cout} @{HW}^2 k{k} pro={pro}: {nb} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us (incl. launch gap); us after first entry:")
 for wv in (0, 1):
     for i, nm in enumerate(names):
         v = (t[:, wv, i] - t0) / 100.0
-        print(f"  wave {'0' if wv == 0 else '7'} {nm:16s} min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f}")
+        print(f"  wave {'0' if wv == 0 else '7'} {nm:18s} min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f}")
