@@ -32,6 +32,26 @@ void gg_set_error(const char *fmt, ...);
         if (e_ != hipSuccess) GG_FAIL(GG_ERR_HIP, "HIP launch: %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Kernel arguments reach a wave through scalar loads from the kernarg segment, and the compiler sinks each load to its first use: a
+// kernel that touches its arguments in four places pays four SERIAL scalar round trips before its first memory instruction.
+// gg_pin launders a wave-uniform value through an SGPR: the pinned arguments are fetched in one batch where the pins stand and
+// cannot be re-materialised from the kernarg segment later.  (Pin only what the first memory instructions need: pinning all ~50
+// dwords of a conv descriptor raised the SGPR pressure and was slower.)
+template <class T>
+__device__ __forceinline__ T gg_pin(T v)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "gg_pin: 32- or 64-bit scalars");
+    if constexpr (sizeof(T) == 4) {
+        unsigned u = __builtin_bit_cast(unsigned, v);
+        asm volatile("" : "+s"(u));
+        return __builtin_bit_cast(T, u);
+    } else {
+        unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        asm volatile("" : "+s"(u));
+        return __builtin_bit_cast(T, u);
+    }
+}
+
 __device__ __forceinline__ float gg_silu(float y) { return y / (1.0f + __expf(-y)); }
 
 __device__ __forceinline__ f32x8 gg_bf16x8_to_f32(bf16x8 v)

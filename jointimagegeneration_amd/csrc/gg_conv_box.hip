@@ -37,10 +37,27 @@
 #define GG_STAMP(K) do { } while (0)
 #endif
 
+// Exact division of small non-negative integers by run-time constants: q = (n * ceil(2^32 / d)) >> 32 for n * d < 2^32 (block ids,
+// k-steps and DMA units are all < 2^16).  One s_mul_hi_u32 instead of the ~30-instruction 32-bit division sequence: at batch 1 the
+// ~520 serially issued instructions between kernel entry and the first DMA were 1.1 us of a 10 us kernel (phase stamps).
+struct BoxMagic { unsigned pq, tw, th, nch, nch_last; int Q; };
+__device__ __forceinline__ int gg_mdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
+static unsigned gg_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // d == 1: handled by the caller
+
 template <int TWI, int MT, int CT, int UP, int K3>
-__global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, const int tiles_h, const int tiles_w, const int nstage,
-                                                         const int nch_stage, const int gn_bytes, const int q_major, const int nblocks)
+__global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg, const int tiles_h_arg, const int tiles_w_arg, const int nstage_arg,
+                                                         const int nch_stage_arg, const int gn_bytes_arg, const int q_major_arg, const int nblocks_arg, const BoxMagic mg_arg)
 {
+    // the arguments the block decode and the first DMAs need, in ONE scalar-load batch (gg_pin); the rest load lazily
+    ConvParams p = p_arg;
+    p.N = gg_pin(p_arg.N); p.H = gg_pin(p_arg.H); p.W = gg_pin(p_arg.W); p.C1 = gg_pin(p_arg.C1); p.C2 = gg_pin(p_arg.C2);
+    p.nchunk1 = gg_pin(p_arg.nchunk1); p.nchunk = gg_pin(p_arg.nchunk); p.src1 = gg_pin(p_arg.src1); p.src2 = gg_pin(p_arg.src2);
+    p.bias = gg_pin(p_arg.bias); p.bias_stride = gg_pin(p_arg.bias_stride); p.prologue_act = gg_pin(p_arg.prologue_act);
+    const int tiles_h = gg_pin(tiles_h_arg), tiles_w = gg_pin(tiles_w_arg), nstage = gg_pin(nstage_arg), nch_stage = gg_pin(nch_stage_arg),
+              gn_bytes = gg_pin(gn_bytes_arg), q_major = gg_pin(q_major_arg), nblocks = gg_pin(nblocks_arg);
+    BoxMagic mg;
+    mg.pq = gg_pin(mg_arg.pq); mg.tw = gg_pin(mg_arg.tw); mg.th = gg_pin(mg_arg.th); mg.nch = gg_pin(mg_arg.nch);
+    mg.nch_last = gg_pin(mg_arg.nch_last); mg.Q = gg_pin(mg_arg.Q);
     // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
     constexpr int TW = TWI, NW = 8;
     constexpr int RPT = 16 / TWI;
@@ -78,15 +95,19 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 
     // ---- workgroup -> (position tile, cout tile).  Consecutive hardware ids round-robin over the 8 XCDs; give every XCD a
     //      contiguous run of virtual ids, then decode them cout-major (a run shares weights) or position-major (shares boxes).
-    const int P = p.N * tiles_h * tiles_w, Q = nblocks / P;
+    const int P = p.N * tiles_h * tiles_w, Q = mg.Q;
     int v = blockIdx.x;
     if ((nblocks & 7) == 0) v = (v & 7) * (nblocks >> 3) + (v >> 3);
-    const int by = q_major ? v / P : v % Q;
-    int t = q_major ? v - by * P : v / Q;
+    // (divisors of 1 have magic 0: the quotient is the dividend)
+    auto mdiv = [](int a, int d, unsigned m) { return d == 1 ? a : gg_mdiv(a, m); };
+    const int vq = mdiv(v, q_major ? P : Q, mg.pq);                     // v / P (cout-major) or v / Q (position-major)
+    const int by = q_major ? vq : v - vq * Q;
+    int t = q_major ? v - vq * P : vq;
     const int stripe = t & (GG_ACC_STRIPES - 1);       // GroupNorm accumulator stripe of this position tile
-    const int tw = t % tiles_w; t /= tiles_w;
-    const int th = t % tiles_h;
-    const int n = t / tiles_h;
+    const int t1 = mdiv(t, tiles_w, mg.tw);
+    const int tw = t - t1 * tiles_w;
+    const int n = mdiv(t1, tiles_h, mg.th);
+    const int th = t1 - n * tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
     const int g = CT == 2 ? by : by >> 1, half = CT == 2 ? 0 : by & 1;
     const int ih0 = UP ? h0 / 2 - 1 : h0 - PADK;
@@ -98,35 +119,22 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co_thr);
 
+    // accumulators, weight base and operand lane offsets are set up AFTER the first stage's DMAs have been issued (a wave issues its
+    // instructions one by one: whatever precedes the DMAs delays the landing of the box)
     f32x4 acc[MT][CT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const bf16_t *wbase = p.weight + ((long long)g * NTAPS * p.nchunk << 10) + half * 512;
-    const int wl0 = fr * 32 + swz64(fr, fq) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
+    const bf16_t *wbase = nullptr;
+    int wl0 = 0;
+    int lane_off[3] = {0, 0, 0};
 
     // staging duty of a lane inside a 16-row DMA block: row (lane>>2), LDS slot (lane&3)
     const int lrow = lane >> 2, lslot = lane & 3;
-
-    // per-lane part of the activation-operand address for the three kw taps (1x1: one)
-    int lane_off[3] = {0, 0, 0};
-    if constexpr (LINE_SWZ) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int rwk = UP ? ((pos_c + k + 1) >> 1) : (pos_c + k);
-            lane_off[k] = (UP ? 0 : pos_r * (HW * 64)) + rwk * 64 + ((fq ^ bsw(0, rwk)) * 16);
-        }
-    } else if constexpr (!K3) {
-        lane_off[0] = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
-    }
 
     for (int st = 0; st < nstage; ++st) {
         const int cbase = st * nch_stage;
         const int nch = (p.nchunk - cbase < nch_stage) ? p.nchunk - cbase : nch_stage;
         const int S = NTAPS * nch;
         const int s0 = (S * wave) / NW, s1 = (S * (wave + 1)) / NW;
+        const unsigned mnch = nch == nch_stage ? mg.nch : mg.nch_last;       // magic of this stage's chunk count
 
         // GroupNorm scale/shift rows of the stage -> LDS, by DMA as well (256 floats per wave instruction)
         if (p.prologue_act) {
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         unsigned vmask = 0u;
         const int cnt = u1 - u0;
         {
-            int rbk = u0 / nch, c = u0 - rbk * nch;
+            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
             setup(rbk);
 #pragma unroll
             for (int j = 0; j < MAXU; ++j) {
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         // (block, chunk) bookkeeping per unit; 15 units per wave).  Hence runs: within one 16-row block and one source tensor,
         // consecutive chunks are +64 B in global memory and +PLANE in LDS, and nothing else changes.
         {
-            int rbk = u0 / nch, c = u0 - rbk * nch;
+            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
             int left = u1 - u0;
             GG_STAMP(8);
             while (left > 0) {
@@ -227,9 +235,27 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         }
 #endif
         GG_STAMP(1);
+        if (st == 0) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wbase = p.weight + ((long long)g * NTAPS * p.nchunk << 10) + half * 512;
+            wl0 = fr * 32 + swz64(fr, fq) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
+            // per-lane part of the activation-operand address for the three kw taps (1x1: one)
+            if constexpr (LINE_SWZ) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int rwk = UP ? ((pos_c + k + 1) >> 1) : (pos_c + k);
+                    lane_off[k] = (UP ? 0 : pos_r * (HW * 64)) + rwk * 64 + ((fq ^ bsw(0, rwk)) * 16);
+                }
+            } else if constexpr (!K3) {
+                lane_off[0] = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
+            }
+        }
         // ---- weight stream of this wave: steps s in [s0, s1), s = tap * nch + c.  Loads past the end re-read the last tile
         //      (unconditional, branch-free: the vmcnt counts stay exact).  Issued AFTER the box so the box lands first.
-        int ltap = s0 / nch, lc = s0 - ltap * nch, lidx = s0;          // load iterator
+        int ltap = mdiv(s0, nch, mnch), lc = s0 - ltap * nch, lidx = s0;          // load iterator
         bf16x8 wr[NTRIP][4][CT];
         auto load_w = [&](bf16x8 (&a)[4][CT]) {
 #pragma unroll
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         GG_STAMP(2);
 #ifdef GG_BOX_REG_STAGE
         {   // registers -> LDS (rows past the box and padding rows are written as zeros: their slots are never read / must be zero)
-            int rbk = u0 / nch, c = u0 - rbk * nch;
+            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
 #pragma unroll
             for (int j = 0; j < MAXU; ++j) {
                 if (j < cnt) {
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
         // this wave's DMAs have landed once only its NTRIP*4*CT weight loads are outstanding; then zero ITS padding slots; then barrier
         __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * 4 * CT));
         if (ih0 < 0 || iw0 < 0 || ih0 + HH > p.H || iw0 + HW > p.W) {        // border workgroups only (wave-uniform)
-            int rbk = u0 / nch, c = u0 - rbk * nch;
+            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
             setup(rbk);
 #pragma unroll 1
             for (int u = u0; u < u1; ++u) {
@@ -314,7 +340,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p, con
 
         GG_STAMP(3);
         // ---- this wave's k-steps: 4 per trip
-        int ctap = s0 / nch, cc = s0 - ctap * nch;          // compute iterator
+        int ctap = mdiv(s0, nch, mnch), cc = s0 - ctap * nch;          // compute iterator
         auto trip = [&](const bf16x8 (&a)[4][CT], int s) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -545,8 +571,11 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     }
     const int tiles_h = (p.Ho + MT * (16 / TWI) - 1) / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
+    const int Pn = p.N * tiles_h * tiles_w, Qn = p.Cout_pad / (16 * CT);
+    const int nch_last = p.nchunk - (pl.nstage - 1) * pl.nch_stage;
+    const BoxMagic mg = {gg_magic(pl.q_major ? Pn : Qn), gg_magic(tiles_w), gg_magic(tiles_h), gg_magic(pl.nch_stage), gg_magic(nch_last), Qn};
     hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
-                       pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x);
+                       pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x, mg);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
