@@ -52,6 +52,20 @@ __device__ __forceinline__ T gg_pin(T v)
     }
 }
 
+// Integer division is a ~30 (32-bit) to ~150 (64-bit) instruction sequence on this ISA, and a wave issues its instructions one by
+// one: in the launch-bound kernels of the latent UNet an index division IS microseconds.
+// gg_fastdiv: n / d through one multiply-high; exact for 0 <= n, n * d < 2^32 (gg_magic_u32 returns 0 when that does not hold or
+// d == 1: plain division then).  gg_div_small: n / d for 0 <= n < 2^21 through the fp32 reciprocal (rcp = v_rcp_f32 of d, 1 ulp).
+__device__ __forceinline__ long long gg_fastdiv(long long n, int d, unsigned magic)
+{
+    return magic ? (long long)__umulhi((unsigned)n, magic) : n / d;
+}
+__device__ __forceinline__ int gg_div_small(int n, float rcp) { return (int)(((float)n + 0.5f) * rcp); }
+static inline unsigned gg_magic_u32(long long nmax, int d)
+{
+    return (d > 1 && nmax * (long long)d < (1LL << 32)) ? (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d) : 0u;
+}
+
 __device__ __forceinline__ float gg_silu(float y) { return y / (1.0f + __expf(-y)); }
 
 __device__ __forceinline__ f32x8 gg_bf16x8_to_f32(bf16x8 v)

@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
                                                              const float *__restrict__ beta, float eps, float *__restrict__ scale,
                                                              float *__restrict__ shift)
 {
+    // every argument in one scalar-load batch (gg_pin)
+    s1 = gg_pin(s1); C1 = gg_pin(C1); s2 = gg_pin(s2); C2 = gg_pin(C2); S = gg_pin(S); C_logical = gg_pin(C_logical);
+    gamma = gg_pin(gamma); beta = gg_pin(beta); eps = gg_pin(eps); scale = gg_pin(scale); shift = gg_pin(shift);
     const int C = C1 + C2;
     const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int cpg = C_logical / 32;
@@ -135,11 +138,12 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     const int p_lo = c_lo >> 3, p_hi = (c_hi - 1) >> 3;
     const int np = p_hi - p_lo + 1;
-    const long long work = S * np;
-    for (long long i = tid; i < work; i += 256) {
-        const long long r = i / np;
-        const int c0 = (p_lo + (int)(i - r * np)) * 8;
-        const bf16_t *src = (c0 < C1) ? b1 + r * C1 + c0 : b2 + r * C2 + (c0 - C1);
+    const int work = (int)S * np;                       // < 2^19 (host gate: S * C <= 2^19)
+    const float rnp = __builtin_amdgcn_rcpf((float)np);
+    for (int i = tid; i < work; i += 256) {
+        const int r = gg_div_small(i, rnp);
+        const int c0 = (p_lo + (i - r * np)) * 8;
+        const bf16_t *src = (c0 < C1) ? b1 + (long long)r * C1 + c0 : b2 + (long long)r * C2 + (c0 - C1);
         const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -185,6 +189,9 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
                                                              long long S, const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float eps, int act, bf16_t *__restrict__ out)
 {
+    // every argument in one scalar-load batch (gg_pin)
+    s1 = gg_pin(s1); C1 = gg_pin(C1); s2 = gg_pin(s2); C2 = gg_pin(C2); S = gg_pin(S); gamma = gg_pin(gamma); beta = gg_pin(beta);
+    eps = gg_pin(eps); act = gg_pin(act); out = gg_pin(out);
     const int C = C1 + C2;
     const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / 32;
@@ -197,13 +204,14 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
     const int p_lo = c_lo >> 3, p_hi = (c_hi - 1) >> 3;
     const int np = p_hi - p_lo + 1;
     const int work = (int)S * np;
+    const float rnp = __builtin_amdgcn_rcpf((float)np);
     u32x4 v[GG_GN_FUSED_MAXP];
 #pragma unroll
     for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
         const int i = tid + 256 * k;
         v[k] = u32x4{0u, 0u, 0u, 0u};
         if (i < work) {
-            const int r = i / np;
+            const int r = gg_div_small(i, rnp);
             const int c0 = (p_lo + (i - r * np)) * 8;
             v[k] = *reinterpret_cast<const u32x4 *>((c0 < C1) ? b1 + (long long)r * C1 + c0 : b2 + (long long)r * C2 + (c0 - C1));
         }
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
     for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
         const int i = tid + 256 * k;
         if (i < work) {
-            const int r = i / np;
+            const int r = gg_div_small(i, rnp);
             const int c0 = (p_lo + (i - r * np)) * 8;
             const bf16x8 x = __builtin_bit_cast(bf16x8, v[k]);
 #pragma unroll
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
     for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
         const int i = tid + 256 * k;
         if (i < work) {
-            const int r = i / np;
+            const int r = gg_div_small(i, rnp);
             const int c0 = (p_lo + (i - r * np)) * 8;
             const bf16x8 x = __builtin_bit_cast(bf16x8, v[k]);
             bf16x8 y;
@@ -352,16 +360,18 @@ extern "C" int gg_groupnorm_stats(const void *src1, int32_t C1, const void *src2
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t *__restrict__ s1, int C1, const bf16_t *__restrict__ s2,
                                                        int C2, long long S, long long total_pieces,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       int act, bf16_t *__restrict__ out)
+                                                       int act, bf16_t *__restrict__ out, unsigned pmagic, int N)
 {
+    // every argument in one scalar-load batch (gg_pin)
+    s1 = gg_pin(s1); C1 = gg_pin(C1); s2 = gg_pin(s2); C2 = gg_pin(C2); S = gg_pin(S); total_pieces = gg_pin(total_pieces);
+    scale = gg_pin(scale); shift = gg_pin(shift); act = gg_pin(act); out = gg_pin(out); pmagic = gg_pin(pmagic); N = gg_pin(N);
     const int C = C1 + C2;
     const int P = C >> 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_pieces;
-         i += (long long)gridDim.x * blockDim.x) {
-        long long row = i / P;                 // row over N*S
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_pieces; i += (long long)gridDim.x * 256) {
+        long long row = gg_fastdiv(i, P, pmagic);                 // row over N*S
         int piece = (int)(i - row * P);
         int c0 = piece * 8;
-        int n = (int)(row / S);
+        int n = N == 1 ? 0 : (int)(row / S);
         const bf16_t *src = (c0 >= C1) ? s2 + row * C2 + (c0 - C1) : s1 + row * C1 + c0;
         bf16x8 v = *reinterpret_cast<const bf16x8 *>(src);
         const float *sc = scale + (long long)n * C + c0;
@@ -391,7 +401,7 @@ extern "C" int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t *)src1, C1,
-                       (const bf16_t *)src2, C2, (long long)S, total, scale, shift, act, (bf16_t *)out);
+                       (const bf16_t *)src2, C2, (long long)S, total, scale, shift, act, (bf16_t *)out, gg_magic_u32(total, (C1 + C2) / 8), N);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -406,12 +416,17 @@ extern "C" int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2
 __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restrict__ s1, int C1, const long long *__restrict__ acc1,
                                                            const bf16_t *__restrict__ s2, int C2, const long long *__restrict__ acc2,
                                                            long long S, int C_logical, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, float eps, int act, bf16_t *__restrict__ out)
+                                                           const float *__restrict__ beta, float eps, int act, bf16_t *__restrict__ out, unsigned pmagic)
 {
+    // every argument in one scalar-load batch (gg_pin)
+    s1 = gg_pin(s1); C1 = gg_pin(C1); acc1 = gg_pin(acc1); s2 = gg_pin(s2); C2 = gg_pin(C2); acc2 = gg_pin(acc2); S = gg_pin(S);
+    C_logical = gg_pin(C_logical); gamma = gg_pin(gamma); beta = gg_pin(beta); eps = gg_pin(eps); act = gg_pin(act); out = gg_pin(out);
+    pmagic = gg_pin(pmagic);
     const int C = C1 + C2;
     const int P = C >> 3;
     const int tid = threadIdx.x, n = blockIdx.y;
     const int cpg = C_logical / 32;
+    const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
     extern __shared__ float ss[];                      // scale[C], shift[C]
     __shared__ unsigned long long gacc[32][2];         // per-group integer (sum, sumsq): LDS atomics, exact in any order
     __shared__ float gmean[32], grstd[32];
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         const long long i = i0 + u * stride;
         pv[u] = u32x4{0u, 0u, 0u, 0u};
         if (i < pieces) {
-            const long long row = i / P;
+            const long long row = gg_fastdiv(i, P, pmagic);
             const int c0 = (int)(i - row * P) * 8;
             pv[u] = *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0);
         }
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
         if (c < C_logical) {
-            const int g = c / cpg;
+            const int g = gg_div_small(c, rcpg);
             atomicAdd(&gacc[g][0], (unsigned long long)sa[k]);
             atomicAdd(&gacc[g][1], (unsigned long long)sb[k]);
         }
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         if (c < C) {
             float sc = 0.f, sh = 0.f;
             if (c < C_logical) {
-                const int g = c / cpg;
+                const int g = gg_div_small(c, rcpg);
                 sc = grstd[g] * gam[k];
                 sh = bet[k] - gmean[g] * sc;
             }
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     }
     __syncthreads();
     auto emit = [&](long long i, const u32x4 raw) {
-        const long long row = i / P;
+        const long long row = gg_fastdiv(i, P, pmagic);
         const int c0 = (int)(i - row * P) * 8;
         const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ss + c0), a1 = *reinterpret_cast<const f32x4 *>(ss + c0 + 4);
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     for (int u = 0; u < U; ++u)
         if (i0 + u * stride < pieces) emit(i0 + u * stride, pv[u]);
     for (long long i = i0 + U * stride; i < pieces; i += stride) {
-        const long long row = i / P;
+        const long long row = gg_fastdiv(i, P, pmagic);
         const int c0 = (int)(i - row * P) * 8;
         emit(i, *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0));
     }
@@ -539,7 +554,7 @@ extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(gn_apply_acc_kernel, dim3((unsigned)blocks, N), dim3(256), C * 2 * sizeof(float), stream, (const bf16_t *)src1, C1,
                        (const long long *)acc1, (const bf16_t *)src2, C2, (const long long *)acc2, (long long)S, C_logical, gamma, beta, eps,
-                       act, (bf16_t *)out);
+                       act, (bf16_t *)out, gg_magic_u32(pieces, C / 8));
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
