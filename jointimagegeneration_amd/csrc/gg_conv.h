@@ -20,6 +20,8 @@ struct ConvParams {
     const float *ddim_scalars;
     bf16_t *ddim_unet_in;
     long long ddim_unet_in_stride;
+    // multiply-high magics (gg_fastdiv) of the output-position decode m -> (n, od, oh, ow); 0 where M * divisor >= 2^32
+    unsigned mg_osp, mg_ohw, mg_wo;
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

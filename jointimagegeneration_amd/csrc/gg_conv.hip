@@ -278,10 +278,10 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
         long long m = m0 + xrow;
         rv = m < p.M;
         unsigned mu = rv ? (unsigned)m : 0u;
-        unsigned n = mu / osp, r = mu - n * osp;
-        unsigned od = r / ohw;
+        unsigned n = (unsigned)gg_fastdiv(mu, (int)osp, p.mg_osp), r = mu - n * osp;
+        unsigned od = (unsigned)gg_fastdiv(r, (int)ohw, p.mg_ohw);
         r -= od * ohw;
-        unsigned oh = r / (unsigned)p.Wo, ow = r - oh * (unsigned)p.Wo;
+        unsigned oh = (unsigned)gg_fastdiv(r, p.Wo, p.mg_wo), ow = r - oh * (unsigned)p.Wo;
         bd = (p.kd == 1) ? (int)od * p.stride : (int)od * p.stride - p.pad;
         bh = (p.kh == 1) ? (int)oh * p.stride : (int)oh * p.stride - p.pad;
         bw = (p.kw == 1) ? (int)ow * p.stride : (int)ow * p.stride - p.pad;
@@ -304,10 +304,18 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
     // k-steps: (group of 5 chunks) outer, tap inner
     const int ngrp = p.nchunk / CPS, ngrp1 = p.nchunk1 / CPS;
     const int KS_all = ngrp * p.ntaps;
-    const int ks_begin = (int)(((long long)KS_all * blockIdx.z) / p.splitk);
-    const int ks_end = (int)(((long long)KS_all * (blockIdx.z + 1)) / p.splitk);
-    int grp = ks_begin / p.ntaps, tap = ks_begin - grp * p.ntaps;
-    int tkd = tap / (p.kh * p.kw), tkh = (tap / p.kw) % p.kh, tkw = tap % p.kw;
+    // (the common cases decode without a division: a wave issues its instructions one by one, and the ten divisions of the general
+    // decode were ~300 of the ~650 instructions in front of this kernel's first load)
+    int ks_begin = 0, ks_end = KS_all;
+    if (p.splitk != 1) {
+        ks_begin = (int)(((long long)KS_all * blockIdx.z) / p.splitk);
+        ks_end = (int)(((long long)KS_all * (blockIdx.z + 1)) / p.splitk);
+    }
+    int grp = ks_begin, tap = 0, tkd = 0, tkh = 0, tkw = 0;
+    if (p.ntaps != 1) {
+        grp = ks_begin / p.ntaps; tap = ks_begin - grp * p.ntaps;
+        tkd = tap / (p.kh * p.kw); tkh = (tap / p.kw) % p.kh; tkw = tap % p.kw;
+    }
 
     u32x4 xreg[2][CPS], wreg[2][3];
     int xso[2];
@@ -642,6 +650,7 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.gn_acc = (long long *)d->gn_acc;
     p.ddim_x = d->ddim_x; p.ddim_pred_x0 = d->ddim_pred_x0; p.ddim_scalars = d->ddim_scalars;
     p.ddim_unet_in = (bf16_t *)d->ddim_unet_in; p.ddim_unet_in_stride = d->ddim_unet_in_stride;
+    p.mg_osp = gg_magic_u32(p.M, d->Do * d->Ho * d->Wo); p.mg_ohw = gg_magic_u32(p.M, d->Ho * d->Wo); p.mg_wo = gg_magic_u32(p.M, d->Wo);
 }
 
 static bool halo_try_dry(const ConvParams &p) { return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK; }
