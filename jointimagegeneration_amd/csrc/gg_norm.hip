@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     const int C = C1 + C2;
     const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int cpg = C_logical / 32;
-    const long long total = S * cpg;
     const bf16_t *b1 = s1 + (long long)n * S * C1;
     const bf16_t *b2 = s2 ? s2 + (long long)n * S * C2 : nullptr;
     float a = 0.f, b = 0.f;
@@ -164,11 +163,13 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
     __syncthreads();
     const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
-    const double cnt = (double)total;
-    const double mean = sa / cnt;
-    double var = sb / cnt - mean * mean;
+    // (no fp64 division / square root: each is a ~50-100-instruction sequence every thread would issue between the reduction and
+    // its stores; the same formulas as gn_apply_acc_kernel: fp32 reciprocal of the exact count, v_rsq_f32)
+    const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 (host gate S * C <= 2^19)
+    const double mean = sa * inv;
+    double var = sb * inv - mean * mean;
     if (var < 0.0) var = 0.0;
-    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean, frstd = rsqrtf((float)var + eps);
     if (tid < cpg) {
         const int c = g * cpg + tid;
         const float sc = frstd * gmm;
@@ -243,11 +244,11 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
     if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
     __syncthreads();
     const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
-    const double cnt = (double)S * (double)cpg;
-    const double mean = sa / cnt;
-    double var = sb / cnt - mean * mean;
+    const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32; no fp64 division / sqrt (see above)
+    const double mean = sa * inv;
+    double var = sb * inv - mean * mean;
     if (var < 0.0) var = 0.0;
-    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean, frstd = rsqrtf((float)var + eps);
 #pragma unroll
     for (int k = 0; k < GG_GN_FUSED_MAXP; ++k) {
         const int i = tid + 256 * k;
