@@ -65,6 +65,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // Weight trips (4 k-steps each) kept in flight per wave: measured on the latent-UNet forward (same box, hipGraph replay):
     // 1 trip 1707 us, 2 trips 1675, 3 trips (CT 1) 1694, 6 / 4 trips where the registers allow 1744.  What a CU can take in is the
     // bound, so weight tiles requested early only delay the landing of the box, i.e. the start of the k-loop.
+    // A deeper ring topped up AFTER the box has landed (6 / 4 trips, host-gated to shares that fill it) is slower too (1648 vs 1606 us):
+    // the phase stamps show the k-loop at the same 3.5-3.8 us either way, i.e. it is not a latency chain but the same intake bound.
     constexpr int NTRIP = 2;
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
