@@ -98,6 +98,14 @@ typedef struct {
     float *ddim_pred_x0;         /* fp32 CL [M, 4] or NULL                                                 */
     void *ddim_unet_in;          /* bf16 CL [M, ddim_unet_in_stride] or NULL                               */
     int64_t ddim_unet_in_stride;
+    /* Optional fused GEGLU epilogue of the feed-forward projection (ldm/modules/attention.py:37-44 `x, gate = proj(x).chunk(2);
+     * x * gelu(gate)`; replaces a separate gg_geglu launch and the round trip of the [M, 2*inner] projection).  1x1(x1) conv, bf16
+     * output, Cout = 2*inner with inner % 16 == 0, no residual, and the weight / bias rows arranged in groups of 32 as [16 value rows
+     * j0..j0+15 | their 16 gate rows inner+j0..inner+j0+15]: the output then has inner channels, out[m, j] =
+     * (acc_value + bias_value)[j] * gelu_erf((acc_gate + bias_gate)[j]) from the fp32 accumulators, row stride Cout_pad / 2.
+     * 0 = plain conv. */
+    int32_t epilogue_geglu;
+    int32_t reserved_tail;
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */

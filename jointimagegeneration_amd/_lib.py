@@ -25,6 +25,7 @@ class ConvDesc(C.Structure):
         ("src1", vp), ("src2", vp), ("weight", vp), ("bias", vp), ("bias_stride", i64),
         ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("reserved_ptr", vp), ("gn_acc", vp),
         ("ddim_x", vp), ("ddim_scalars", vp), ("ddim_pred_x0", vp), ("ddim_unet_in", vp), ("ddim_unet_in_stride", i64),
+        ("epilogue_geglu", i32), ("reserved_tail", i32),
     ]
 
 

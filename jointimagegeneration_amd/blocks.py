@@ -86,6 +86,24 @@ def packed_cat(mods: List[nn.Module], cin_pad: int, tag: str):
     return PACKED.get((id(mods[0]), cin_pad, tag), params, build)
 
 
+def packed_geglu(proj: nn.Module, cin_pad: int):
+    """GEGLU projection (attention.py:37-44) packed for the fused epilogue (gg_conv_desc.epilogue_geglu): rows in groups of 32 =
+    [16 value rows j0..j0+15 | their 16 gate rows inner+j0..inner+j0+15], bias likewise."""
+    def build():
+        w, b = proj.weight, proj.bias
+        inner = w.shape[0] // 2
+        assert inner % 16 == 0
+        j = torch.arange(inner, device=w.device).view(-1, 16)                       # [inner/16, 16] value rows
+        order = torch.cat([j, j + inner], 1).reshape(-1)                            # value block, gate block, value block, ...
+        pw = ops.pack_conv_weight(w[order][:, :, None], cin_pad)
+        pb = ops.pad_bias(b[order] if b is not None else None, w.shape[0], w.device)
+        return pw, pb
+    return PACKED.get((id(proj), cin_pad, "geglu"), [proj.weight, getattr(proj, "bias", None)], build)
+
+
+FUSE_GEGLU = True     # feed-forward projection with the GEGLU as its epilogue (False: projection, then gg_geglu)
+
+
 def f32(p: torch.Tensor) -> torch.Tensor:
     return p.detach().float().contiguous()
 
@@ -307,11 +325,15 @@ class BasicTransformerBlock(nn.Module):
         x = self.attn2.run(self._ln(x, self.norm2), context, x)
         y = self._ln(x, self.norm3)
         proj, lin2 = self.ff.net[0].proj, self.ff.net[2]
-        pw, pb = packed_conv(proj, y.Cpad)
-        hcl = ops.conv(y, pw, pb, proj.weight.shape[0], k=(1, 1, 1), pad=0)
-        gg = ops.geglu(hcl.t, self.ff.inner)
+        if FUSE_GEGLU and self.ff.inner % 16 == 0:
+            pw, pb = packed_geglu(proj, y.Cpad)
+            ggcl = ops.conv(y, pw, pb, proj.weight.shape[0], k=(1, 1, 1), pad=0, geglu=True)      # value * gelu(gate) from the fp32 accumulators
+        else:
+            pw, pb = packed_conv(proj, y.Cpad)
+            hcl = ops.conv(y, pw, pb, proj.weight.shape[0], k=(1, 1, 1), pad=0)
+            ggcl = CL(ops.geglu(hcl.t, self.ff.inner), self.ff.inner)
         pw2, pb2 = packed_conv(lin2, self.ff.inner)
-        return ops.conv(CL(gg, self.ff.inner), pw2, pb2, lin2.weight.shape[0], k=(1, 1, 1), pad=0, residual=x)
+        return ops.conv(ggcl, pw2, pb2, lin2.weight.shape[0], k=(1, 1, 1), pad=0, residual=x)
 
 
 class SpatialTransformer(nn.Module):

@@ -22,6 +22,7 @@ struct ConvParams {
     long long ddim_unet_in_stride;
     // multiply-high magics (gg_fastdiv) of the output-position decode m -> (n, od, oh, ow); 0 where M * divisor >= 2^32
     unsigned mg_osp, mg_ohw, mg_wo;
+    int epi_geglu;            // gg_conv_desc.epilogue_geglu (generic gather kernel without split-K only)
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

@@ -212,6 +212,36 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         // 3.66 vs 2.70 ms per latent-UNet forward, an agent-scope release per K-slice block costs more than the reduce launch)
         return;
     }
+    if (p.epi_geglu) {
+        // ---- GEGLU epilogue (gg_conv_desc.epilogue_geglu): cout tile 2k holds 16 value channels, tile 2k+1 their gates, so a lane has
+        //      both halves of its 4 output channels in registers; out[m, j] = value * gelu_erf(gate), inner = Cout / 2 channels
+        const int ostride = p.Cout_pad >> 1, inner = p.Cout >> 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long long m = m0 + wave * 32 + pt * 16 + fr;
+            if (m >= p.M) continue;
+            const int n = (int)((unsigned)m / osp);
+            const float *brow = p.bias ? p.bias + (long long)n * p.bias_stride : nullptr;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int co = (g0 * 32) + k * 32 + fq * 4;            // value rows co.., gate rows co + 16..
+                f32x4 v = acc[pt][2 * k], g = acc[pt][2 * k + 1];
+                if (brow) {
+                    v += *reinterpret_cast<const f32x4 *>(brow + co);
+                    g += *reinterpret_cast<const f32x4 *>(brow + co + 16);
+                }
+                const int oc = (co >> 5) * 16 + fq * 4;                 // output channel of the lane's first element
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float ge = 0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f));   // F.gelu, exact erf form (as gg_geglu)
+                    ob[j] = (bf16_t)((oc + j < inner) ? v[j] * ge : 0.f);
+                }
+                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + m * ostride + oc) = ob;
+            }
+        }
+        return;
+    }
     // ---- epilogue: + bias[n] (+ residual) -> bf16 / fp32, 4 consecutive channels per lane
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -625,7 +655,7 @@ static int plan_gather5(long long M, int C1, int C2, int Cout_pad, int ntaps)
 
 extern "C" int64_t gg_conv_workspace_bytes(const gg_conv_desc *d)
 {
-    if (!d) return 0;
+    if (!d || d->epilogue_geglu) return 0;           // (the GEGLU epilogue runs on the single-pass gather kernel)
     long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     int KS = d->kd * d->kh * d->kw * ((d->C1 + d->C2) / 32);
     if (int tsk = gg_conv_tiny_plan(M, d->Cout_pad, KS, d->prologue_act)) return tsk > 1 ? (int64_t)tsk * M * d->Cout_pad * 4 : 0;
@@ -650,6 +680,7 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.gn_acc = (long long *)d->gn_acc;
     p.ddim_x = d->ddim_x; p.ddim_pred_x0 = d->ddim_pred_x0; p.ddim_scalars = d->ddim_scalars;
     p.ddim_unet_in = (bf16_t *)d->ddim_unet_in; p.ddim_unet_in_stride = d->ddim_unet_in_stride;
+    p.epi_geglu = d->epilogue_geglu;
     p.mg_osp = gg_magic_u32(p.M, d->Do * d->Ho * d->Wo); p.mg_ohw = gg_magic_u32(p.M, d->Ho * d->Wo); p.mg_wo = gg_magic_u32(p.M, d->Wo);
 }
 
@@ -657,7 +688,7 @@ static bool halo_try_dry(const ConvParams &p) { return gg_conv_halo_try(p, (hipS
 
 extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 {
-    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32) return 0;
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu) return 0;
     ConvParams p;
     fill_params(d, p);
     if (gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK) return 1;
@@ -683,7 +714,7 @@ extern "C" int gg_conv_fuses_ddim(const gg_conv_desc *d)
 // Which path a desc takes is decided by the same plan functions gg_conv_forward uses.
 extern "C" int gg_conv_emits_stats(const gg_conv_desc *d)
 {
-    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->out_dtype != GG_BF16) return 0;
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->out_dtype != GG_BF16 || d->epilogue_geglu) return 0;
     ConvParams p;
     fill_params(d, p);
     if (halo_try_dry(p)) return GG_ACC_STRIPES_HALO;
@@ -726,6 +757,20 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
     if (p.M >= (1LL << 31) || (long long)d->D * d->H * d->W * (d->C1 > d->C2 ? d->C1 : d->C2) >= (1LL << 31))
         GG_FAIL(GG_ERR_UNSUPPORTED, "conv: tensor too large for 32-bit in-sample offsets");
 
+    if (d->epilogue_geglu) {
+        // fused GEGLU epilogue: implemented in the generic gather kernel's single-pass (no split-K) epilogue only
+        if (d->kd != 1 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->upsample || d->residual || d->out_dtype != GG_BF16 || d->gn_acc ||
+            d->ddim_x || d->Cout % 32 || d->bias_stride)
+            GG_FAIL(GG_ERR_UNSUPPORTED, "conv: the GEGLU epilogue needs a 1x1 conv, bf16 output, Cout = 2*inner with inner %% 16 == 0, a shared bias, no residual / gn_acc / ddim");
+        const GatherPlan plg = plan_gather(p.M, p.Cout_pad, p.ntaps * p.nchunk);
+        switch (plg.NT) {
+            case 5: return launch_gather<5>(p, stream);
+            case 4: return launch_gather<4>(p, stream);
+            case 3: return launch_gather<3>(p, stream);
+            case 2: return launch_gather<2>(p, stream);
+            default: return launch_gather<1>(p, stream);
+        }
+    }
     int rc = gg_conv_halo_try(p, stream);
     if (rc != GG_ERR_UNSUPPORTED) return rc;
 #ifdef GG_BOX_STAMPS

@@ -213,7 +213,7 @@ def _stats_alloc(device, N: int, cp: int, stripes: int) -> Optional[torch.Tensor
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
-         out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None) -> CL:
+         out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None, geglu: bool = False) -> CL:
     """ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
     runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step."""
     lib = _lib.load()
@@ -221,6 +221,10 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     N, D, H, W, C1 = t1.shape
     Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
     cp = pad32(cout)
+    if geglu:      # fused GEGLU epilogue (gg_conv_desc.epilogue_geglu): cout = 2 * inner value | gate rows in, inner channels out
+        if cout % 32 or out is not None or out_f32 or residual is not None:
+            raise ValueError("conv(geglu=True): cout = 2 * inner with inner % 16 == 0, bf16 output, no residual")
+        out = torch.empty((N, Do, Ho, Wo, cp // 2), dtype=torch.bfloat16, device=t1.device)
     if out is None:
         out = torch.empty((N, Do, Ho, Wo, cp), dtype=torch.float32 if out_f32 else torch.bfloat16, device=t1.device)
     d = ConvDesc()
@@ -242,6 +246,7 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     d.out = out.data_ptr()
     d.gn_scale = _ptr(prologue[0]) if prologue is not None else None
     d.gn_shift = _ptr(prologue[1]) if prologue is not None else None
+    d.epilogue_geglu = 1 if geglu else 0
     wsb = lib.gg_conv_workspace_bytes(C.byref(d))
     if wsb > 0:
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=t1.device)
@@ -264,7 +269,7 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         d.ddim_unet_in_stride = uin.shape[-1] if uin is not None else 0
         fused = True
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
-    return CL(out, cout, acc=acc, fused_ddim=fused)
+    return CL(out, cout // 2 if geglu else cout, acc=acc, fused_ddim=fused)
 
 
 # ----------------------------------------------------------------------------------------------- norms / elementwise

@@ -516,6 +516,45 @@ def test_layernorm_geglu_add_linear_embedding(dev):
     assert rel_err(ops.timestep_embedding(T(tg["t_i"]).float().to(dev), 160), T(tg["emb_i"])) < 2e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 50, 320, 1280), (1, 256, 64, 256), (1, 7, 96, 48), (3, 1024, 160, 640)], ids=lambda c: "N%dT%dC%di%d" % c)
+def test_feed_forward_projection_with_geglu_epilogue(dev, shape, monkeypatch):
+    """GEGLU as the epilogue of the feed-forward projection (gg_conv_desc.epilogue_geglu; attention.py:37-44): == value * gelu(gate) of
+    the fp32 projection of the bf16-rounded operands, and == the two-launch path (projection rounded to bf16, then gg_geglu) up to
+    that rounding; the whole BasicTransformerBlock gives the same output either way within a bf16 ulp or two."""
+    from jointimagegeneration_amd import blocks as B
+    from jointimagegeneration_amd import ops
+    N, Tn, Cc, inner = shape
+    g = torch.Generator().manual_seed(Tn + inner)
+    x = torch.randn(N, Tn, Cc, generator=g)
+    proj = torch.nn.Linear(Cc, 2 * inner)
+    with torch.no_grad():
+        proj.weight.copy_(torch.randn(2 * inner, Cc, generator=g) / math.sqrt(Cc)); proj.bias.copy_(0.3 * torch.randn(2 * inner, generator=g))
+    proj = proj.to(dev)
+    h = F.linear(bf(x), bf(proj.weight.cpu()), proj.bias.cpu())
+    a, gate = h.chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    xcl = ops.CL(torch.zeros(N, 1, 1, Tn, ops.pad32(Cc), dtype=torch.bfloat16, device=dev), Cc)
+    xcl.t[..., :Cc] = x.to(dev).view(N, 1, 1, Tn, Cc)
+    pw, pb = B.packed_geglu(proj, xcl.Cpad)
+    got = ops.conv(xcl, pw, pb, 2 * inner, k=(1, 1, 1), pad=0, geglu=True)
+    assert got.C == inner and got.t.shape[-1] == ops.pad32(2 * inner) // 2
+    assert rel_err(got.t[..., :inner].float().view(N, Tn, inner).cpu(), ref) < 6e-3
+    pw0, pb0 = B.packed_conv(proj, xcl.Cpad)
+    two = ops.geglu(ops.conv(xcl, pw0, pb0, 2 * inner, k=(1, 1, 1), pad=0).t, inner)
+    assert rel_err(got.t[..., :inner].float(), two.float()) < 1.5e-2          # the two-launch path rounds the projection to bf16 first
+    with pytest.raises(ValueError):
+        ops.conv(xcl, pw, pb, 2 * inner, k=(1, 1, 1), pad=0, geglu=True, residual=got)
+    if Cc == 64:
+        blk = seeded(B.BasicTransformerBlock(64, 2, 32, context_dim=48), "geglu_blk.").to(dev)
+        xin = ops.CL((0.5 * torch.randn(1, 1, 1, Tn, 64, generator=g)).to(dev).bfloat16(), 64)
+        ctx = ops.CL(torch.zeros(1, 1, 1, 9, 64, dtype=torch.bfloat16, device=dev), 48)
+        ctx.t[..., :48] = torch.randn(1, 1, 1, 9, 48, generator=g).to(dev)
+        fused = blk.run(xin, ctx).t.float()
+        monkeypatch.setattr(B, "FUSE_GEGLU", False)
+        plain = blk.run(xin, ctx).t.float()
+        assert float((fused - plain).abs().max()) <= 2.0 ** -6 * float(plain.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("cfg", [(2, 2, 32, 128), (1, 8, 32, 512), (2, 3, 32, 64), (1, 1, 64, 64), (1, 1, 512, 96), (1, 1, 384, 40), (1, 4, 128, 70)],
                          ids=lambda c: f"N{c[0]}h{c[1]}d{c[2]}T{c[3]}")
