@@ -84,8 +84,8 @@ typedef struct {
     int64_t *gn_acc;           /* optional [N][S][Cout_pad][2] int64 (S = gg_conv_emits_stats(desc) stripes by position tile, summed by the consumer), caller-zeroed: the epilogue adds, per output channel, the sum
                                   and the sum of squares of the bf16-rounded outputs in fixed point (2^28 / 2^20 fractional
                                   bits; integer atomics commute, so the result is bit-reproducible).  It is the GroupNorm
-                                  statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc (4 stripes) or gg_groupnorm_scale_shift_acc.
-                                  Only filled when gg_conv_emits_stats(desc) != 0, which also gives the stripe count (4: box / 160-step
+                                  statistics of the NEXT norm, consumed by gg_groupnorm_apply_acc (the 1-stripe layout of the box / 160-step kernels) or gg_groupnorm_scale_shift_acc.
+                                  Only filled when gg_conv_emits_stats(desc) != 0, which also gives the stripe count (1: box / 160-step
                                   kernels without split-K; 32: halo-tile kernel); bf16 output only. */
     /* Optional fused DDIM update as the epilogue of the UNet HEAD conv (ldm/models/diffusion/ddim.py:190-204; replaces a separate
      * gg_ddim_step launch).  Only when gg_conv_fuses_ddim(desc) == 1 (box kernel, Cout == 4 == channels of the state, fp32 output): for
@@ -121,7 +121,7 @@ int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
  * then skip the separate gg_groupnorm_apply pass); 0 if it runs on the generic gather kernel. Pointers are not read. */
 int gg_conv_fuses_prologue(const gg_conv_desc *desc);
 /* 0 if gg_conv_forward(desc) will not fill desc->gn_acc, else the number of stripes S of the [N][S][Cout_pad][2] accumulator it fills
- * (4 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
+ * (1 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
 int gg_conv_emits_stats(const gg_conv_desc *desc);
 /* 1 if gg_conv_forward(desc) can run the fused DDIM epilogue (see gg_conv_desc.ddim_x); pointers are not read. */
 int gg_conv_fuses_ddim(const gg_conv_desc *desc);

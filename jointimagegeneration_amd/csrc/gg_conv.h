@@ -28,8 +28,11 @@ struct ConvParams {
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample
 #define GG_ACC_SUM_SCALE 268435456.0f   /* 2^28 */
 #define GG_ACC_SQ_SCALE 1048576.0f      /* 2^20 */
-// accumulators are striped [N][GG_ACC_STRIPES][C][2] by position tile, so that at most P/4 workgroups add to one address
-#define GG_ACC_STRIPES 4
+// accumulators of the box / 160-step kernels: [N][GG_ACC_STRIPES][C][2].  One stripe: at most a few dozen position tiles add to
+// one address, and every block of gn_apply_acc re-reads all stripes (4 stripes: 1606 us per latent-UNet forward, 1 stripe: 1595)
+#ifndef GG_ACC_STRIPES
+#define GG_ACC_STRIPES 1
+#endif
 // the halo-tile kernel (thousands of workgroups per launch) stripes 32-way: at most P/32 workgroups add to one address
 #define GG_ACC_STRIPES_HALO 32
 

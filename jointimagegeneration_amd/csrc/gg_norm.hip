@@ -1,6 +1,6 @@
 // GroupNorm(32) statistics + fused normalise*affine(+SiLU), LayerNorm, GEGLU, add. HBM-bound kernels:
 // 16-byte (8 x bf16) accesses per lane, fp32 math, two-source aware (fused skip concat).
-#include "gg_common.h"
+#include "gg_conv.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // Stage 1: per-block partial sums. grid = (nblk, N). Block b of sample n owns rows [b*rpb, (b+1)*rpb).
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
             pv[u] = *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0);
         }
     }
-    // this thread's channels: 4 stripes x (sum, sumsq) as 16-byte loads, gamma / beta; everything requested before the first wait
+    // this thread's channels: GG_ACC_STRIPES x (sum, sumsq) as 16-byte loads, gamma / beta; everything requested before the first wait
     float gam[CPT], bet[CPT];
     long long sa[CPT], sb[CPT];
 #pragma unroll
@@ -461,11 +461,11 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         sa[k] = 0;
         sb[k] = 0;
         if (c < C_logical) {
-            const long long *q = (c < C1) ? acc1 + ((long long)n * 4 * C1 + c) * 2 : acc2 + ((long long)n * 4 * C2 + (c - C1)) * 2;
+            const long long *q = (c < C1) ? acc1 + ((long long)n * GG_ACC_STRIPES * C1 + c) * 2 : acc2 + ((long long)n * GG_ACC_STRIPES * C2 + (c - C1)) * 2;
             const long long cs = (c < C1) ? (long long)C1 * 2 : (long long)C2 * 2;
             typedef __attribute__((ext_vector_type(2))) long long i64x2;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < GG_ACC_STRIPES; ++st) {
                 const i64x2 v = *reinterpret_cast<const i64x2 *>(q + st * cs);
                 sa[k] += v[0];
                 sb[k] += v[1];

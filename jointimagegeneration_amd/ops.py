@@ -202,7 +202,7 @@ def stats_end(device) -> None:
 
 def _stats_alloc(device, N: int, cp: int, stripes: int) -> Optional[torch.Tensor]:
     a = _ARENAS.get(str(device))
-    n = N * stripes * cp * 2            # stripes: 4 (box / 160-step kernels, GG_ACC_STRIPES) or 32 (halo-tile kernel)
+    n = N * stripes * cp * 2            # stripes: 1 (box / 160-step kernels, GG_ACC_STRIPES) or 32 (halo-tile kernel)
     if a is None or not a["active"] or a["off"] + n > _ARENA_ENTRIES:
         return None
     v = a["buf"][a["off"]:a["off"] + n].view(N, stripes, cp, 2)
@@ -253,7 +253,7 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
     acc = None
     if GN_ACC and d.out_dtype == GG_BF16:
-        # box / 160-step kernels (4 stripes): only where the norm is launch-bound; halo-tile kernel (32 stripes): always -- there the
+        # box / 160-step kernels (1 stripe): only where the norm is launch-bound; halo-tile kernel (32 stripes): always -- there the
         # sums replace a statistics PASS over a 17..805 MB tensor
         stripes = lib.gg_conv_emits_stats(C.byref(d))
         if stripes == 32 or (stripes and GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS):
@@ -342,8 +342,8 @@ def groupnorm_apply_acc(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: 
 
 
 def has_stats(src1: CL, src2: Optional[CL] = None) -> bool:
-    """the producing convs left 4-stripe accumulators: gg_groupnorm_apply_acc can normalise without a statistics launch"""
-    ok = lambda c: c is None or (c.acc is not None and c.acc.shape[1] == 4)
+    """the producing convs (box / 160-step kernels) left their accumulators: gg_groupnorm_apply_acc can normalise without a statistics launch"""
+    ok = lambda c: c is None or (c.acc is not None and c.acc.shape[1] != 32)       # box / 160-step producers (GG_ACC_STRIPES), not the halo kernel's 32
     return GN_ACC and src1.acc is not None and ok(src1) and ok(src2) and src1.Cpad + (src2.Cpad if src2 is not None else 0) <= 2048
 
 
