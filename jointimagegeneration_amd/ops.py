@@ -175,7 +175,7 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 # network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
 GN_ACC = True
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
-GN_ACC_MIN_ELEMS = 1 << 18          # below this the one-launch statistics kernel is as fast (5 us)
+GN_ACC_MIN_ELEMS = 1 << 17          # below this the one-launch GroupNorm kernels are as fast (probe_gn_acc_min.py: 2^18 1593, 2^17 1586, 2^16 1590, 2^15 1604 us per forward)
 _ARENA_ENTRIES = 1 << 19            # 4 MiB of int64 (the latent UNet at batch 1 uses ~0.4 M entries)
 _ARENAS = {}
 
