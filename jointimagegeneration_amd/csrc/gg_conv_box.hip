@@ -67,7 +67,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // bound, so weight tiles requested early only delay the landing of the box, i.e. the start of the k-loop.
     // A deeper ring topped up AFTER the box has landed (6 / 4 trips, host-gated to shares that fill it) is slower too (1648 vs 1606 us):
     // the phase stamps show the k-loop at the same 3.5-3.8 us either way, i.e. it is not a latency chain but the same intake bound.
-    constexpr int NTRIP = 2;
+#ifndef GG_BOX_NTRIP_K3
+#define GG_BOX_NTRIP_K3 2
+#endif
+    constexpr int NTRIP = K3 ? GG_BOX_NTRIP_K3 : 2;
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
@@ -255,22 +258,39 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                 lane_off[0] = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
             }
         }
-        // ---- weight stream of this wave: steps s in [s0, s1), s = tap * nch + c.  Loads past the end re-read the last tile
-        //      (unconditional, branch-free: the vmcnt counts stay exact).  Issued AFTER the box so the box lands first.
-        int ltap = mdiv(s0, nch, mnch), lc = s0 - ltap * nch, lidx = s0;          // load iterator
-        bf16x8 wr[NTRIP][4][CT];
-        auto load_w = [&](bf16x8 (&a)[4][CT]) {
+        // ---- weight stream of this wave.  3x3: the wave owns units q in [q0, q1) of the (kh, chunk) grid, a unit = the three kw taps
+        //      of one chunk plane and one kh, so kw is a compile-time constant in the k-loop (operand lane offsets, weight tile stride)
+        //      and the scalar bookkeeping is paid once per three k-steps: at batch 1 the k-loop was bound by its ~50 scalar / branch
+        //      instructions per k-step, not by the 3-12 MFMAs in it (a deeper weight ring did not shorten it).  1x1: steps = chunks,
+        //      four per trip.  Loads past the end re-read the last unit (unconditional, branch-free: the vmcnt counts stay exact).
+        //      Issued AFTER the box so the box lands first.
+        constexpr int SPT = K3 ? 3 : 4;                                           // k-steps per trip
+        const int TU = K3 ? 3 * nch : nch;                                        // trips-units of the stage: (kh, chunk) units / chunks
+        const int q0 = K3 ? (TU * wave) / NW : s0, q1 = K3 ? (TU * (wave + 1)) / NW : s1;
+        int lkh = K3 ? mdiv(q0, nch, mnch) : 0, lc = q0 - lkh * nch, lidx = q0;   // load iterator
+        bf16x8 wr[NTRIP][SPT][CT];
+        auto load_w = [&](bf16x8 (&a)[SPT][CT]) {
+            if constexpr (K3) {
+                const bf16_t *tile = wbase + (((long long)(lkh * 3) * p.nchunk + cbase + lc) << 10) + wl0;
+                const long long kws = (long long)p.nchunk << 10;                  // next tap of the same chunk
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bf16_t *tile = wbase + (((long long)ltap * p.nchunk + cbase + lc) << 10) + wl0;
+                for (int u = 0; u < 3; ++u)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
-                const int adv = (lidx + 1 < s1) ? 1 : 0;
+                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);
+                const int adv = (lidx + 1 < q1) ? 1 : 0;
                 lidx += adv;
                 lc += adv;
                 const int wrap = (lc == nch) ? 1 : 0;
                 lc = wrap ? 0 : lc;
-                ltap += wrap;
+                lkh += wrap;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bf16_t *tile = wbase + ((long long)(cbase + lc) << 10) + wl0;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                    lc += (lc + 1 < q1) ? 1 : 0;
+                }
             }
         };
         asm volatile("" ::: "memory");                 // keep the weight loads behind the DMA issue
@@ -296,8 +316,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         // the GroupNorm rows (DMA, issued before the box loads) have landed with the box loads; only the weight trips are still out
         GG_BOX_LDS_BARRIER();
 #else
-        // this wave's DMAs have landed once only its NTRIP*4*CT weight loads are outstanding; then zero ITS padding slots; then barrier
-        __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * 4 * CT));
+        // this wave's DMAs have landed once only its NTRIP*SPT*CT weight loads are outstanding; then zero ITS padding slots; then barrier
+        __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * SPT * CT));
         if (ih0 < 0 || iw0 < 0 || ih0 + HH > p.H || iw0 + HW > p.W) {        // border workgroups only (wave-uniform)
             int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
             setup(rbk);
@@ -341,60 +361,66 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         }
 
         GG_STAMP(3);
-        // ---- this wave's k-steps: 4 per trip
-        int ctap = mdiv(s0, nch, mnch), cc = s0 - ctap * nch;          // compute iterator
-        auto trip = [&](const bf16x8 (&a)[4][CT], int s) {
+        // ---- this wave's k-steps
+        int ckh = K3 ? mdiv(q0, nch, mnch) : 0, cc = q0 - ckh * nch;            // compute iterator: (kh, chunk) unit / chunk
+        auto kstep = [&](const bf16x8 (&w)[CT], const char *plane, const int kh, const int kw) {     // kw: compile-time after unrolling
+            bf16x8 xf[MT];
+            if constexpr (LANE_ADDR) {
+                const int lo = lane_off[K3 ? kw : 0];
+                if constexpr (!UP) {
+                    const char *pa = plane + kh * (HW * 64) + lo;                 // one VALU add per k-step
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (s + u < s1) {
-                    const int kh = K3 ? ctap / 3 : 0, kw = K3 ? ctap - kh * 3 : 0;
-                    const char *plane = box + cc * PLANE;
-                    bf16x8 xf[MT];
-                    if constexpr (LANE_ADDR) {
-                        const int lo = K3 ? (kw == 0 ? lane_off[0] : (kw == 1 ? lane_off[1] : lane_off[2])) : lane_off[0];
-                        if constexpr (!UP) {
-                            const char *pa = plane + kh * (HW * 64) + lo;                 // one VALU add per k-step
-#pragma unroll
-                            for (int tt = 0; tt < MT; ++tt) xf[tt] = *reinterpret_cast<const bf16x8 *>(pa + tt * (K3 ? RPT * HW * 64 : 1024));
-                        } else {                                                          // TWI == 16: line (tt + kh + 1) >> 1
-                            const char *pe = plane + ((kh + 1) >> 1) * (HW * 64) + lo, *po = plane + ((kh + 2) >> 1) * (HW * 64) + lo;
-#pragma unroll
-                            for (int tt = 0; tt < MT; ++tt)
-                                xf[tt] = *reinterpret_cast<const bf16x8 *>(((tt & 1) ? po : pe) + (tt >> 1) * (HW * 64));
-                        }
-                    } else {
-                        const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
-#pragma unroll
-                        for (int tt = 0; tt < MT; ++tt) {
-                            const int orow = tt * RPT + pos_r;
-                            const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
-                            const int row = hh * HW + rwk;
-                            xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
-                        }
-                    }
-                    // all MT operand reads are issued before the first MFMA (the scheduler would otherwise pair them two by two to save
-                    // registers and expose the LDS latency once per pair); the MFMAs then drain them under counted lgkmcnt
-                    if constexpr (MT * CT <= 12) __builtin_amdgcn_sched_barrier(0);      // (12 x 2: the 48 operand registers would spill)
+                    for (int tt = 0; tt < MT; ++tt) xf[tt] = *reinterpret_cast<const bf16x8 *>(pa + tt * (K3 ? RPT * HW * 64 : 1024));
+                } else {                                                          // TWI == 16: line (tt + kh + 1) >> 1
+                    const char *pe = plane + ((kh + 1) >> 1) * (HW * 64) + lo, *po = plane + ((kh + 2) >> 1) * (HW * 64) + lo;
 #pragma unroll
                     for (int tt = 0; tt < MT; ++tt)
+                        xf[tt] = *reinterpret_cast<const bf16x8 *>(((tt & 1) ? po : pe) + (tt >> 1) * (HW * 64));
+                }
+            } else {
+                const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][ct], xf[tt], acc[tt][ct], 0, 0, 0);
-                    if (++cc == nch) { cc = 0; ++ctap; }
+                for (int tt = 0; tt < MT; ++tt) {
+                    const int orow = tt * RPT + pos_r;
+                    const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
+                    const int row = hh * HW + rwk;
+                    xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
                 }
             }
+            // all MT operand reads are issued before the first MFMA (the scheduler would otherwise pair them two by two to save
+            // registers and expose the LDS latency once per pair); the MFMAs then drain them under counted lgkmcnt
+            if constexpr (MT * CT <= 12) __builtin_amdgcn_sched_barrier(0);      // (12 x 2: the 48 operand registers would spill)
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ct], xf[tt], acc[tt][ct], 0, 0, 0);
         };
-        int s = s0;
+        auto trip = [&](const bf16x8 (&a)[SPT][CT], int q) {
+            if constexpr (K3) {
+                if (q < q1) {
+                    const char *plane = box + cc * PLANE;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) kstep(a[kw], plane, ckh, kw);
+                    if (++cc == nch) { cc = 0; ++ckh; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q + u < q1) { kstep(a[u], box + cc * PLANE, 0, 0); ++cc; }
+            }
+        };
+        int q = q0;
 #pragma unroll 1
-        for (; s + 4 * NTRIP < s1; s += 4 * NTRIP) {       // steady state: at least one of the refilled trips is real
+        for (; q + (K3 ? 1 : 4) * NTRIP < q1; q += (K3 ? 1 : 4) * NTRIP) {       // steady state: at least one of the refilled trips is real
 #pragma unroll
             for (int r = 0; r < NTRIP; ++r) {
-                trip(wr[r], s + 4 * r);
+                trip(wr[r], q + (K3 ? 1 : 4) * r);
                 load_w(wr[r]);
             }
         }
 #pragma unroll
-        for (int r = 0; r < NTRIP; ++r) trip(wr[r], s + 4 * r);      // drain: nothing left to load
+        for (int r = 0; r < NTRIP; ++r) trip(wr[r], q + (K3 ? 1 : 4) * r);      // drain: nothing left to load
         GG_STAMP(4);
         GG_BOX_WAIT_BARRIER(0);   // all waves done with the box: it may be overwritten (next stage / the reduction area)
         GG_STAMP(5);
