@@ -1,22 +1,28 @@
 // Box-resident 2-D convolution for UNDER-FILLED grids (latent UNet levels at batch 1: 64x64 .. 16x16, 160..1280 channels):
 // 3x3 (stride 1, pad 1, optional fused nearest x2 upsample) and 1x1, bf16 in / fp32 accumulate on v_mfma_f32_16x16x32_bf16.
 //
-// These layers are 1-8 GFLOP each: neither MFMA nor HBM bound, but bound by what ONE CU can take in (measured 50-70 GB/s
-// per CU from L2, MI355X_MICROARCH.md "Indexed rows") and by exposed round trips.  The kernel therefore (a) moves the
-// minimum number of bytes into each CU, (b) has every byte in flight at once, and (c) has no barrier in its main loop:
+// These layers are 1-8 GFLOP each: neither MFMA nor HBM bound, but bound by (1) what ONE CU can take in (tools/experiments/
+// ubench_intake.hip: 48 GB/s per CU for 64-byte rows, 70 for 128-byte lines, ~80 contiguous, L2-resident, 240 workgroups) and (2) the
+// number of instructions a wave has to issue, one by one, in front of and between its memory instructions (~2 ns each at one or two
+// waves per SIMD: phase stamps, -DGG_BOX_STAMPS).  The kernel therefore moves the minimum number of bytes into each CU, has every
+// byte of the box in flight at once, has no barrier in its main loop, and keeps its scalar bookkeeping out of the inner loops:
 //   * a workgroup (8 waves) owns MT position tiles (16 positions each: 1x16, 2x8 or 4x4, so 8x8 and 4x4 levels fit too) x 16*CT
-//     output channels; the plan (plan_box) picks MT and CT so
-//     that max-over-CUs of (weight slice + input box) bytes is smallest for a single round of <= 256 workgroups;
-//   * the input box the 9 taps touch ((TH+2) x 18 rows; upsample: (TH/2+2) x 10) is staged into LDS ONCE for ALL input
-//     channels of a stage (<= 128 KiB; two-source concat and zero padding applied here) as one swizzled 64-byte-row plane
-//     per 32-channel chunk.  Every 16-row block of a plane is one global_load_lds wave instruction: the whole box is in
-//     flight at once and costs no VGPRs.  GroupNorm affine (* SiLU) then runs IN PLACE in LDS, once per staged element,
-//     while the weight stream is still arriving;
-//   * the (tap, chunk) k-steps of the stage are split evenly over the 8 waves.  Each wave streams the weight tiles of ITS
-//     k-steps straight from L2 into VGPRs (ring of 2-3 trips x 4 steps, counted vmcnt; no LDS copy, no redundancy between
-//     waves) and reads the activation operand from the LDS box at a shifted row;
-//   * the partial accumulators of the 8 waves are combined through LDS in a fixed order (deterministic), then bias /
-//     residual / store;
+//     output channels; the plan (plan_box) picks MT and CT so that max-over-CUs of (weight slice + input box) bytes is smallest for
+//     a single round of <= 256 workgroups; block ids decode by multiply-high with host-provided magics, and the arguments the
+//     first DMAs need are pinned into one scalar-load batch (gg_pin);
+//   * the input box the 9 taps touch ((TH+2) x 18 rows; upsample: (TH/2+2) x 10) is staged into LDS ONCE for ALL input channels
+//     of a stage (<= 128 KiB; two-source concat and zero padding applied here) as one swizzled 64-byte-row plane per 32-channel
+//     chunk, by global_load_lds (1 KiB = 16 rows per wave instruction, no VGPRs).  Units (16-row block, chunk) are walked
+//     block-major in runs: consecutive chunks are +64 B in memory (the two halves of a 128-byte line go out back to back) and
+//     +PLANE in LDS, 6.5 instructions per unit; padding slots are zeroed by the issuing wave after its DMAs have landed.
+//     GroupNorm affine (* SiLU), where fused (<= 2 cout tiles per box), then runs IN PLACE in LDS, once per staged element;
+//   * the k-steps of the stage are split evenly over the 8 waves as (kh, chunk) units with the three kw taps unrolled (kw is a
+//     compile-time constant: operand addresses are lane constant + uniform + immediate, the bookkeeping is paid once per three
+//     k-steps).  Each wave streams the weight tiles of ITS units straight from L2 into VGPRs (ring of 2 units, counted vmcnt; no
+//     LDS copy, no redundancy between waves; deeper rings are slower: the stream is intake-bound) and reads the activation operand
+//     from the LDS box at a shifted row, all MT reads of a k-step ahead of its MFMAs;
+//   * the partial accumulators of the 8 waves are combined through LDS in a fixed order (deterministic), then bias / residual /
+//     store (+ GroupNorm sums of the next norm, + the fused DDIM update on the UNet head);
 //   * workgroups are renumbered so that the ones sharing a weight slice (weight-heavy layers) or an input box
 //     (activation-heavy layers) run on the same XCD and hit its L2 (blockIdx round-robins over the 8 XCDs).
 #include "gg_conv.h"
