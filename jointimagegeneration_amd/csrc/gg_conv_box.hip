@@ -73,10 +73,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // bound, so weight tiles requested early only delay the landing of the box, i.e. the start of the k-loop.
     // A deeper ring topped up AFTER the box has landed (6 / 4 trips, host-gated to shares that fill it) is slower too (1648 vs 1606 us):
     // the phase stamps show the k-loop at the same 3.5-3.8 us either way, i.e. it is not a latency chain but the same intake bound.
-#ifndef GG_BOX_NTRIP_K3
-#define GG_BOX_NTRIP_K3 2
-#endif
-    constexpr int NTRIP = K3 ? GG_BOX_NTRIP_K3 : 2;
+    constexpr int NTRIP = 2;        // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
@@ -180,32 +177,6 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         };
         const char *s1n = reinterpret_cast<const char *>(p.src1 + (long long)n * p.H * p.W * p.C1);
         const char *s2n = reinterpret_cast<const char *>(p.src2 + (long long)n * p.H * p.W * p.C2);
-#ifdef GG_BOX_REG_STAGE
-        // Through registers: the phase stamps showed that a wave's global_load_lds instructions of scattered 64-byte rows go out one
-        // per ~250 ns (10 DMAs: 2.5 us before the last one is even issued, with 50 or with 240 workgroups on the chip), while plain
-        // 16-byte loads issue back to back and share one round trip.  A wave has at most MAXU = 16 units (128 KiB of box / 1 KiB / 8).
-        constexpr int MAXU = 16;
-        u32x4 sv[MAXU];
-        unsigned vmask = 0u;
-        const int cnt = u1 - u0;
-        {
-            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
-            setup(rbk);
-#pragma unroll
-            for (int j = 0; j < MAXU; ++j) {
-                sv[j] = u32x4{0u, 0u, 0u, 0u};
-                if (j < cnt) {
-                    const int gc = cbase + c;
-                    const bool second = gc >= p.nchunk1;
-                    const char *sb = second ? s2n + (gc - p.nchunk1) * 64 : s1n + gc * 64;      // wave-uniform
-                    const unsigned off = valid ? (second ? off2 : off1) : 0u;                   // padding: any legal address, zeroed below
-                    sv[j] = *reinterpret_cast<const u32x4 *>(sb + off);
-                    vmask |= valid ? (1u << j) : 0u;
-                    if (++c == nch) { c = 0; ++rbk; setup(rbk); }
-                }
-            }
-        }
-#else
         // DMA issue: every lane always issues (padding and past-the-box rows from a clamped, legal address; the padding slots are
         // zeroed by their own wave after its DMAs have landed, below).  A wave issues its instructions one by one, so the instruction
         // count per unit IS the staging time at batch 1 (stamps: 170 ns per unit with a predicated DMA / zero-store pair and the
@@ -244,7 +215,6 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                 ++rbk;
             }
         }
-#endif
         GG_STAMP(1);
         if (st == 0) {
 #pragma unroll
@@ -304,24 +274,6 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
         // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
         GG_STAMP(2);
-#ifdef GG_BOX_REG_STAGE
-        {   // registers -> LDS (rows past the box and padding rows are written as zeros: their slots are never read / must be zero)
-            int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
-#pragma unroll
-            for (int j = 0; j < MAXU; ++j) {
-                if (j < cnt) {
-                    u32x4 d = sv[j];
-                    const bool ok = (vmask >> j) & 1u;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e] = ok ? d[e] : 0u;
-                    *reinterpret_cast<u32x4 *>(box + c * PLANE + rbk * 1024 + lane * 16) = d;
-                    if (++c == nch) { c = 0; ++rbk; }
-                }
-            }
-        }
-        // the GroupNorm rows (DMA, issued before the box loads) have landed with the box loads; only the weight trips are still out
-        GG_BOX_LDS_BARRIER();
-#else
         // this wave's DMAs have landed once only its NTRIP*SPT*CT weight loads are outstanding; then zero ITS padding slots; then barrier
         __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * SPT * CT));
         if (ih0 < 0 || iw0 < 0 || ih0 + HH > p.H || iw0 + HW > p.W) {        // border workgroups only (wave-uniform)
@@ -334,7 +286,6 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             }
         }
         GG_BOX_LDS_BARRIER();
-#endif
 
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
 #pragma unroll 2
