@@ -66,7 +66,9 @@ static inline unsigned gg_magic_u32(long long nmax, int d)
     return (d > 1 && nmax * (long long)d < (1LL << 32)) ? (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d) : 0u;
 }
 
-__device__ __forceinline__ float gg_silu(float y) { return y / (1.0f + __expf(-y)); }
+// SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp), as the conv prologues compute it: an IEEE division is ~10 VALU instructions per
+// element, 16 elements per thread in the launch-bound GroupNorm kernels
+__device__ __forceinline__ float gg_silu(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
 __device__ __forceinline__ f32x8 gg_bf16x8_to_f32(bf16x8 v)
 {
