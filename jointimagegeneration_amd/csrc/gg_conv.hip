@@ -428,6 +428,24 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
         }
     };
 
+    // the epilogue's bias and residual values are requested here, a whole k-loop ahead of their use (an exposed round trip at the end
+    // of a 5-10 us kernel otherwise)
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2e;
+    f32x4 bias_pf[2];
+    u32x2e res_pf[2];
+    {
+        const long long mp = m0 + wave * 16 + fr;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int co = g0 * 32 + ct * 16 + fq * 4;
+            bias_pf[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            res_pf[ct] = u32x2e{0u, 0u};
+            if (mp < p.M && p.splitk == 1) {
+                if (p.bias) bias_pf[ct] = *reinterpret_cast<const f32x4 *>(p.bias + (long long)((unsigned)mp / osp) * p.bias_stride + co);
+                if (p.residual) res_pf[ct] = *reinterpret_cast<const u32x2e *>(p.residual + mp * p.Cout_pad + co);
+            }
+        }
+    }
     const int KS = ks_end - ks_begin;
     if (KS > 0) load_regs(xreg[0], wreg[0], xso[0]);
     if (KS > 1) load_regs(xreg[1], wreg[1], xso[1]);
@@ -461,9 +479,9 @@ __global__ __launch_bounds__(256) void conv_gather5_kernel(const ConvParams p)
             *reinterpret_cast<f32x4 *>(p.ws + (long long)blockIdx.z * p.M * p.Cout_pad + o) = v;
             continue;
         }
-        if (p.bias) v += *reinterpret_cast<const f32x4 *>(p.bias + (long long)((unsigned)m / osp) * p.bias_stride + co);
+        v += bias_pf[ct];
         if (p.residual) {
-            const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+            const bf16x4 r = __builtin_bit_cast(bf16x4, res_pf[ct]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
         }
