@@ -66,8 +66,8 @@ typedef struct {
     int32_t path_hint;         /* 0 = production dispatch.  1 (tests only) = take the halo-tile kernel whenever the shape is inside
                                   its envelope, even when the grid would under-fill the chip (the production gate then prefers
                                   the box / split-K kernels): lets small test shapes exercise the kernel the big shapes use, with its
-                                  512-position box.  4 (tests only) = the same with the 256-position box the production dispatch
-                                  picks for 3-D grids of <= 256 workgroups */
+                                  512-position box.  4 / 6 (tests only) = the same with the 256-position box the production dispatch
+                                  picks for 3-D grids of <= 256 workgroups / the 1024-position box it picks for grids of >= 512 */
     const void *src1;          /* bf16 CL [N,D,H,W,C1]                                                   */
     const void *src2;          /* bf16 CL [N,D,H,W,C2] or NULL                                           */
     const void *weight;        /* packed by gg_conv_pack_weight                                          */

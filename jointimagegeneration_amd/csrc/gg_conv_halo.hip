@@ -17,12 +17,14 @@
 #endif
 
 template <int D3, int NT, int UP, int HB>
-__global__ __launch_bounds__((NT <= 2 ? 256 : 512), (HB ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+__global__ __launch_bounds__(((NT <= 2 && HB != 2) ? 256 : 512), (HB == 1 ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? (HB ? 4 : 8) : 32, TW = 16;
+    // HB 0: 512-position box 4x8x16 (2-D: 1x32x16); 1: 256 positions 4x4x16 (under-filled 3-D grids); 2: 1024 positions 8x8x16, one
+    // 8-wave workgroup per CU (halo redundancy 1.76x instead of 2.1x: less staging work per output)
+    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
     // NT <= 2: 4 waves x 8 position-tiles (128 pos x 32*NT couts per wave, 2 workgroups per CU overlap staging and MFMA);
     // NT >= 3: 8 waves x 4 position-tiles (the accumulator would not fit otherwise)
-    constexpr int NWAVE = NT <= 2 ? 4 : 8;
+    constexpr int NWAVE = (NT <= 2 && HB != 2) ? 4 : 8;
     constexpr int TPW = (TD * TH) / NWAVE;
     constexpr int NTHR = NWAVE * 64;
     constexpr int KD = D3 ? 3 : 1;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), (HB ? 3 : 2)) void conv_halo
     constexpr int JMAX = (NPIECE + NTHR - 1) / NTHR;
     constexpr int XBYTES = ((NROWS * 64 + 1023) / 1024) * 1024;
     constexpr int WBYTES = NT * 2048;                    // one tap: 32*NT cout rows x 64 B
-    __shared__ __attribute__((aligned(1024))) char smem[XBYTES + 2 * WBYTES];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // XBYTES + 2 * WBYTES (launch_halo)
     char *xs = smem;
     char *wsm = smem + XBYTES;
 
@@ -286,10 +288,18 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), (HB ? 3 : 2)) void conv_halo
 template <int D3, int NT, int UP, int HB = 0>
 static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
-    constexpr int TD = D3 ? 4 : 1, TH = D3 ? (HB ? 4 : 8) : 32, TW = 16;
+    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
+    constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1, HH = UP ? TH / 2 + 2 : TH + 2, HW = UP ? TW / 2 + 2 : TW + 2;
+    constexpr int LDSB = ((HD * HH * HW * 64 + 1023) / 1024) * 1024 + 2 * NT * 2048;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)conv_halo_kernel<D3, NT, UP, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+            return GG_ERR_UNSUPPORTED;
+        attr_set = true;
+    }
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3(NT <= 2 ? 256 : 512), 0, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3((NT <= 2 && HB != 2) ? 256 : 512), LDSB, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -332,14 +342,22 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (!NT) NT = 1;
     const long long blocks = tiles * (G / NT);
     // under-filled grids: the box / split-K gather paths are faster (2-D under one workgroup per CU: AE 512->512 @64x64 is 136 us
-    // here at 128 workgroups); path_hint 1 / 4 (tests) lift the gate so that small shapes run on this kernel
+    // here at 128 workgroups); path_hint 1 / 4 / 6 (tests) lift the gate so that small shapes run on this kernel
     const long long min_blocks = (d3 || (wide2d && NT > 1)) ? 128 : 256;
-    if (p.path_hint != 1 && p.path_hint != 4 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
+    if (p.path_hint != 1 && p.path_hint != 4 && p.path_hint != 6 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
     // 3-D grids of at most one 512-position workgroup per CU: 256-position boxes (HB: 4x4x16, three workgroups per CU) double the
     // grid; same-box A/B 256->256 @32^3: 141 vs 156 us.  On filled grids the two box sizes are within +-3 % (64->64 @128^3
     // 525-534 vs 519-571 us, 192->64 1464-1467 vs 1370-1442 us), so those keep the box with the smaller halo.
-    // path_hint (tests): 1 = always the 512-position box, 4 = the 256-position box wherever it is instantiated (NT <= 2).
+    // path_hint (tests): 1 = always the 512-position box, 4 = the 256-position box wherever it is instantiated (NT <= 2), 6 = the 1024-one.
+    // 3-D grids that still give every CU a workgroup with 1024-position boxes (8x8x16, one 8-wave workgroup per CU, 124 KiB of LDS):
+    // the halo redundancy drops from 2.1x to 1.76x, i.e. less staging (loads, GroupNorm*SiLU, LDS writes) per output.  Same-box A/B at
+    // 128^3 with the fused prologue: 64->64 500 -> 468 us, 192->64 1338 -> 1240 us, 32->64 300 -> 280 us (bit-identical results);
+    // 256->256 @32^3 would lose (177 vs 156 us: half the workgroups), hence the grid condition.  path_hint 6 (tests) forces it.
+    if (d3 && NT <= 2 && !p.upsample && (p.Do % 8) == 0 && (p.path_hint == 6 || (p.path_hint == 0 && blocks >= 512))) {
+        if (NT == 2) return launch_halo<1, 2, 0, 2>(p, stream);
+        return launch_halo<1, 1, 0, 2>(p, stream);
+    }
     if (d3 && NT <= 2 && (p.path_hint == 4 || (p.path_hint == 0 && blocks <= 256))) {
         if (NT == 2) return p.upsample ? launch_halo<1, 2, 1, 1>(p, stream) : launch_halo<1, 2, 0, 1>(p, stream);
         return p.upsample ? launch_halo<1, 1, 1, 1>(p, stream) : launch_halo<1, 1, 0, 1>(p, stream);

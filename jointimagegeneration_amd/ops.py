@@ -33,7 +33,7 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
                            "(no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")
 
 
-PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 / 4 to run small shapes on the halo-tile kernel (production: 0)
+PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 / 4 / 6 to run small shapes on the halo-tile kernel (production: 0)
 def weights_token(module) -> Tuple[int, int, int]:
     """Cheap identity of a module's current weights: (#tensors, sum of in-place version counters, sum of storage addresses).
     load_state_dict, LitEma.copy_to / restore and optimizer steps write in place (version bump); .to(device) moves storage."""

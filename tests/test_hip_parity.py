@@ -708,7 +708,7 @@ def test_blocks_match_reference_fixtures(dev):
     assert rel_err(ops.from_cl(a2.run(ops.to_cl(T(g["aea_x"]).to(dev))), 2), T(g["aea_y"])) < 3e-2
 
 
-@pytest.mark.parametrize("hint", [0, 1, 4], ids=["production_dispatch", "halo_hint_box512", "halo_hint_box256"])
+@pytest.mark.parametrize("hint", [0, 1, 4, 6], ids=["production_dispatch", "halo_hint_box512", "halo_hint_box256", "halo_hint_box1024"])
 def test_small_networks_match_reference_fixtures(dev, hint, monkeypatch):
     from jointimagegeneration_amd import ops
     monkeypatch.setattr(ops, "PATH_HINT", hint)

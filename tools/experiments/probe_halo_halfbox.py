@@ -16,7 +16,7 @@ for (Cin, Cout, S, pro) in [(64, 64, 128, 1), (192, 64, 128, 1), (128, 128, 64, 
         kw = dict(prologue=(sc, sh))
     outs = {}
     for rnd in range(3):
-        for hint in (1, 4):
+        for hint in (1, 6):
             ops.PATH_HINT = hint
             y = ops.conv(x, pw, pb, Cout, k=(3, 3, 3), **kw); torch.cuda.synchronize()
             outs[hint] = y.t
@@ -27,4 +27,4 @@ for (Cin, Cout, S, pro) in [(64, 64, 128, 1), (192, 64, 128, 1), (128, 128, 64, 
             t = e0.elapsed_time(e1) / 30 * 1e3
             gf = 2.0 * S ** 3 * Cout * Cin * 27 / 1e9
             print(f"{Cin}->{Cout} @{S}^3 pro={pro} hint={hint}: {t:.1f} us ({gf/t*1e3:.0f} TF/s)", flush=True)
-    print("   bit-identical:", bool(torch.equal(outs[1], outs[4])), flush=True)
+    print("   bit-identical:", bool(torch.equal(outs[1], outs[6])), flush=True)
