@@ -149,8 +149,11 @@ int gg_groupnorm_fused_supported(int64_t S, int32_t C1, int32_t C2, int32_t C_lo
 int gg_groupnorm_fused(const void *src1, int32_t C1, const void *src2, int32_t C2, int32_t N, int64_t S, int32_t C_logical,
                        const float *gamma, const float *beta, float eps, int32_t act, void *out, void *stream);
 /* The same normalise*affine(+SiLU), with the statistics taken from the per-channel fixed-point accumulators that the producing
- * convs left behind (gg_conv_desc.gn_acc): acc1 [N][4][C1][2], acc2 [N][4][C2][2] (NULL iff C2 == 0).  Every block folds the
- * accumulators into the per-channel scale/shift table in LDS (fp64), so no statistics launch is needed. */
+ * convs left behind (gg_conv_desc.gn_acc): acc1 [N][1][C1][2], acc2 [N][1][C2][2] (NULL iff C2 == 0) -- ONLY the 1-stripe layout,
+ * i.e. accumulators of convs for which gg_conv_emits_stats(desc) == 1 (box / 160-step kernels); the call has no stripe arguments,
+ * so the 32-stripe accumulators of the halo-tile kernel (gg_conv_emits_stats == 32) must go through gg_groupnorm_scale_shift_acc
+ * instead (handing them here would read 1/32 of the sums without an error).  Every block folds the accumulators into the
+ * per-channel scale/shift table in LDS (fp64), so no statistics launch is needed. */
 int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2, const int64_t *acc2,
                            int32_t N, int64_t S, int32_t C_logical, const float *gamma, const float *beta, float eps,
                            int32_t act, void *out, void *stream);

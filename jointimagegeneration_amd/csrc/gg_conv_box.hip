@@ -25,6 +25,7 @@
 //     store (+ GroupNorm sums of the next norm, + the fused DDIM update on the UNet head);
 //   * workgroups are renumbered so that the ones sharing a weight slice (weight-heavy layers) or an input box
 //     (activation-heavy layers) run on the same XCD and hit its L2 (blockIdx round-robins over the 8 XCDs).
+#include <atomic>
 #include "gg_conv.h"
 #include <stdlib.h>
 
@@ -548,11 +549,15 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
 template <int TWI, int MT, int CT, int UP, int K3>
 static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device ordinal (setting it twice from two threads is harmless)
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GG_ERR_HIP;
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {
         if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
-        attr_set = true;
+        attr_mask.fetch_or(dev_bit, std::memory_order_release);
     }
     const int tiles_h = (p.Ho + MT * (16 / TWI) - 1) / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));

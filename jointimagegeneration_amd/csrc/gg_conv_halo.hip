@@ -10,6 +10,7 @@
 //      weight is pre-swizzled, so the linear DMA image is already the bank-conflict-free one) while the previous tap's
 //      MFMAs run; the activation operand of tap (kd,kh,kw) is the same LDS box read at a shifted row.
 // HBM/L2 traffic per block and chunk: one box (41 KB) instead of 27 gathered tiles (27 x 16 KB) in the generic kernel.
+#include <atomic>
 #include "gg_conv.h"
 #include <stdlib.h>
 #ifndef GG_HALO_WPS
@@ -291,11 +292,15 @@ static int launch_halo(const ConvParams &p, hipStream_t stream)
     constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
     constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1, HH = UP ? TH / 2 + 2 : TH + 2, HW = UP ? TW / 2 + 2 : TW + 2;
     constexpr int LDSB = ((HD * HH * HW * 64 + 1023) / 1024) * 1024 + 2 * NT * 2048;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device ordinal (setting it twice from two threads is harmless)
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GG_ERR_HIP;
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {
         if (hipFuncSetAttribute((const void *)conv_halo_kernel<D3, NT, UP, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
-        attr_set = true;
+        attr_mask.fetch_or(dev_bit, std::memory_order_release);
     }
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
     const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
     // (no fp64 division / square root: each is a ~50-100-instruction sequence every thread would issue between the reduction and
     // its stores; the same formulas as gn_apply_acc_kernel: fp32 reciprocal of the exact count, v_rsq_f32)
-    const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 (host gate S * C <= 2^19)
+    const double cnt = (double)S * (double)cpg; double inv = (double)(1.0f / (float)cnt); inv = inv * (2.0 - cnt * inv);      // fp32 reciprocal + one Newton step in fp64 (error ~1e-14: no fp64 division, and mean^2 is not polluted when |mean| >> std)
     const double mean = sa * inv;
     double var = sb * inv - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
     if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
     __syncthreads();
     const double sa = (ra[0] + ra[1]) + (ra[2] + ra[3]), sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
-    const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32; no fp64 division / sqrt (see above)
+    const double cnt = (double)S * (double)cpg; double inv = (double)(1.0f / (float)cnt); inv = inv * (2.0 - cnt * inv);      // fp32 reciprocal + Newton step in fp64; no fp64 division / sqrt (see above)
     const double mean = sa * inv;
     double var = sb * inv - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     if (tid < 32) {
         const double a = (double)(long long)gacc[tid][0] * (1.0 / GG_ACC_SUM_SCALE_D);
         const double b = (double)(long long)gacc[tid][1] * (1.0 / GG_ACC_SQ_SCALE_D);
-        const double inv = (double)(1.0f / ((float)S * (float)cpg));      // S * cpg < 2^24: exact in fp32 for every shape here
+        const double cnt = (double)S * (double)cpg; double inv = (double)(1.0f / (float)cnt); inv = inv * (2.0 - cnt * inv);      // fp32 reciprocal + Newton step in fp64 (as gn_stats_small)
         const double mean = a * inv;
         double var = b * inv - mean * mean;
         if (var < 0.0) var = 0.0;

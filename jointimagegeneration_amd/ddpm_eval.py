@@ -83,19 +83,23 @@ def main(argv=None):
     # synthetic features here (the hospital reports are private).  The shipped UNet has no SpatialTransformer and ignores the
     # resulting context, exactly as in the reference.
     fce = build_feature_cond_encoder(params)
-    context = None
     if fce is not None:
         path = params.get("load_from")
+        sd_fce = None
         if path and os.path.exists(path):
             ck = load_checkpoint(path)
             sd_fce = ck.get("average_feature_cond_encoder", ck.get("feature_cond_encoder"))
-            if sd_fce is not None:
-                fce.load_state_dict(sd_fce)
-        else:
-            randomize_parameters(fce, 1024, "fce.")
-        fce = fce.eval().to(dev)
-        feats = torch.randn((1, fce.embed_dim, int(params.get("context_length", 512))), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
-        context = fce(feats)
+        try:
+            if sd_fce is not None:      # a DDP / DataParallel-wrapped encoder saves its keys as `module.*` (condition_encoder.py:91-97)
+                fce.load_state_dict({(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd_fce.items()})
+            else:
+                randomize_parameters(fce, 1024, "fce.")
+            fce = fce.eval().to(dev)
+            feats = torch.randn((1, fce.embed_dim, int(params.get("context_length", 512))), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
+            context = fce(feats)        # computed as evaluator.py:166-169 does; the shipped UNet takes no context and ignores it
+            print(f"[rank {rank}] feature_cond_encoder context {tuple(context.shape)} (not consumed by the shipped UNet)", file=sys.stderr)
+        except Exception as e:          # the eval itself does not need the encoder: a mismatching encoder checkpoint must not abort it
+            print(f"[rank {rank}] WARNING: feature_cond_encoder skipped ({type(e).__name__}: {e})", file=sys.stderr)
     out_dir = args.out or os.path.join(params.get("output_path", "."), args.exp_name)
     os.makedirs(out_dir, exist_ok=True)
     init_t = None if args.steps is None else 10000 + args.steps

@@ -216,7 +216,7 @@ class IdentityEncoder(nn.Module):
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     if schedule != "linear":
         raise NotImplementedError("only the 'linear' schedule is used by the shipped configs")
-    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2).numpy()
 
 
 class LitEma(nn.Module):
@@ -549,7 +549,7 @@ class DDIMSampler(object):
         key = (N, Cx, sp3, Cc, str(dev))
         # everything cached below is a function of the schedule (steps, eta -> sigmas) and of the UNet's weights (time-bias
         # table, packed weights baked into the captured graph): a changed schedule or weight version rebuilds the state
-        token = (S, tuple(float(v) for v in self.ddim_sigmas), ops.weights_token(unet))
+        token = (S, tuple(int(v) for v in self.ddim_timesteps), tuple(float(v) for v in self.ddim_sigmas), ops.weights_token(unet))
         st = self._graphs.get(key)
         if st is not None and st["token"] == token:
             return st

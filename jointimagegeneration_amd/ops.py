@@ -36,13 +36,24 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
 PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 / 4 / 6 to run small shapes on the halo-tile kernel (production: 0)
 def weights_token(module) -> Tuple[int, int, int]:
     """Cheap identity of a module's current weights: (#tensors, sum of in-place version counters, sum of storage addresses).
-    load_state_dict, LitEma.copy_to / restore and optimizer steps write in place (version bump); .to(device) moves storage."""
+    load_state_dict, LitEma.copy_to / restore and optimizer steps write in place (version bump); .to(device) moves storage.
+    NOT detected: writes through `p.data` (`p.data.copy_(...)`, as the reference's own ema.py:57-65 does) -- they bypass the
+    version counter.  Code that writes that way must call `invalidate_caches(module)` afterwards."""
     n = v = a = 0
     for p in module.parameters():
         n += 1
         v += p._version
         a += p.data_ptr()
     return n, v, a
+
+
+def invalidate_caches(module) -> None:
+    """Bump the version counter of every parameter (an in-place no-op write), so that every cache keyed by `weights_token` or by
+    (data_ptr, _version) -- repacked weights, time-bias tables, captured hipGraphs -- is rebuilt on the next forward.  For callers
+    that changed weights through `p.data` (invisible to autograd's version counter)."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(0)
 
 
 def capture_graph(fn) -> "torch.cuda.CUDAGraph":

@@ -146,8 +146,10 @@ class GuideGenPipeline:
 
     # ---- stage 2 ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def sample_ct(self, labels: torch.Tensor, depth: int, hw: int, seed: int, max_slices: Optional[int] = None) -> torch.Tensor:
-        """labels int32 [N,Dm,Hm,Wm] -> CT volume fp32 [N, depth, hw, hw] in [0,1]; slice m conditioned on slice m-1."""
+    def sample_ct(self, labels: torch.Tensor, depth: int, hw: int, seed: int, max_slices: Optional[int] = None,
+                  x_T_tape=None) -> torch.Tensor:
+        """labels int32 [N,Dm,Hm,Wm] -> CT volume fp32 [N, depth, hw, hw] in [0,1]; slice m conditioned on slice m-1.
+        `x_T_tape` (parity runs): one [N, Cz, lat, lat] start latent per generated slice, in loop order, instead of the seeded draw."""
         ldm, sampler, S = self.ldm, self.sampler, self.ddim_steps
         dev = labels.device
         N = labels.shape[0]
@@ -177,7 +179,8 @@ class GuideGenPipeline:
             ops.mask_to_cond_slice(labels, mm, depth, hw, hw, prev, cond_in)
             # drawn in the reference's NCHW element order (ddim.py:124 `torch.randn(shape)`), so that a seeded generator gives
             # sample_diffusion.sample_cond and this loop the same x_T; stored channels-last (plumbing copies)
-            x_T = torch.randn((N, Cz, lat, lat), generator=g, device=dev).permute(0, 2, 3, 1).reshape(N, 1, lat, lat, Cz)
+            x_T = x_T_tape[it].to(dev).float() if x_T_tape is not None else torch.randn((N, Cz, lat, lat), generator=g, device=dev)
+            x_T = x_T.permute(0, 2, 3, 1).reshape(N, 1, lat, lat, Cz)
             st["x"].copy_(x_T)
             st["unet_in"][..., :Cz].copy_(x_T)                                         # fp32 -> bf16
             if not (self.use_graph and sampler.chain_graphable(st)):

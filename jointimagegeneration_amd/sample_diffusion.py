@@ -77,9 +77,10 @@ def strip_ckpt_paths(cfg):
 
 
 @torch.no_grad()
-def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise_seed=None, vanilla=False, plms=False):
+def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise_seed=None, vanilla=False, plms=False, x_T_tape=None):
     """The reference slice loop (sample_diffusion.py:196-224) on the reference-shaped API. instance["wholemask"] is
-    [1, D, H, W, 1] (label/255); returns pred [n, 2, D, H, W] = cat([samples, gen_mask])."""
+    [1, D, H, W, 1] (label/255); returns pred [n, 2, D, H, W] = cat([samples, gen_mask]).  `x_T_tape` (parity runs): one
+    [n, C, h, w] start latent per generated slice, in loop order, instead of the generator draw of ddim.py:124."""
     sampler = PLMSSampler(model) if plms else DDIMSampler(model)
     with model.ema_scope():
         wholemask = instance["wholemask"].permute(0, 4, 1, 2, 3).cuda()
@@ -90,10 +91,13 @@ def sample_cond(model, instance, n_samples=1, ddim_steps=50, ddim_eta=0.0, noise
         samples = torch.zeros((n_samples,) + wholemask.shape[1:], dtype=torch.float32, device=wholemask.device)
         gen_mask = wholemask.repeat(n_samples, 1, 1, 1, 1)
         g = torch.Generator(device=wholemask.device).manual_seed(noise_seed) if noise_seed is not None else None
-        for m_ in range(start_layer.item() - 1, end_layer.item() + 1):
+        for it, m_ in enumerate(range(start_layer.item() - 1, end_layer.item() + 1)):
             concat_cond = torch.cat([samples[:, :, max(0, m_ - 1)], gen_mask[:, :, m_]], axis=1)
             c = model.get_learned_conditioning(concat_cond)
-            x_T = torch.randn((n_samples,) + shape, generator=g, device=wholemask.device) if g is not None else None
+            if x_T_tape is not None:
+                x_T = x_T_tape[it].to(wholemask.device).float()
+            else:
+                x_T = torch.randn((n_samples,) + shape, generator=g, device=wholemask.device) if g is not None else None
             if vanilla:
                 s = model.p_sample_loop(c, (n_samples,) + shape, x_T=x_T, verbose=False)
             else:

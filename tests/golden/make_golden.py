@@ -546,6 +546,63 @@ def fx_e2e(dd, oh, un, ldm, which):
         save("e2e_c2", z=z.half(), c_seed=np.array(2048))
 
 
+def fx_autoreg(ldm):
+    """B8: the autoregressive slice loop.  The reference's `sample_cond` itself cannot run here (hard-wired `.cuda()`, PNG dumps
+    through PIL / torchvision into ./samples/layers, latentdiffusion/sample_diffusion.py:199-223), so its LOOP BODY (:206-222) is
+    executed statement by statement on the imported reference LatentDiffusion / DDIMSampler objects: concat_cond -> 
+    get_learned_conditioning -> sampler.sample -> decode_first_stage -> min-max normalise -> feed back; 11 slices, 5 DDIM steps,
+    x_T / per-step noises from a tape in the order ddim.py:124,201 draws them.  oracle.samplers.autoregressive_slices must
+    reproduce every slice before the fixture is written."""
+    om, at, mo, ae, dm, di, ut = ldm
+    import io, contextlib
+    import unittest.mock as mock
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import synth_labels
+    cfg_unet = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(LDM_SMALL))
+    cfg_ae = lambda cin: dict(target="ldm.models.autoencoder.AutoencoderKL",
+                              params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL, in_channels=cin, out_ch=cin),
+                                          lossconfig=dict(target="torch.nn.Identity")))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = dm.LatentDiffusion(first_stage_config=cfg_ae(1), cond_stage_config=cfg_ae(2), unet_config=cfg_unet,
+                               linear_start=0.0015, linear_end=0.0195, timesteps=1000, image_size=8, channels=4, dims=2,
+                               first_stage_key="image", cond_stage_key="mask", num_timesteps_cond=1).eval()
+    randomize_parameters(m, SEED, "ldm_pipe.")
+    D, hw, S_steps, n_samples = 11, 32, 5, 1
+    lab = synth_labels((D, hw, hw), 12, seed=21)
+    lab[0] = 0                                                      # start_layer = 1: the loop begins at m = 0
+    assert lab[1:].reshape(D - 1, -1).any(1).all()
+    wholemask = (torch.from_numpy(lab).float() / 255.0)[None, None]                       # [1, 1, D, H, W]
+    gen = g(8192)
+    shape = (m.channels, m.image_size, m.image_size)
+    tape = [torch.randn((n_samples,) + shape, generator=gen) for _ in range(D * (S_steps + 1))]        # slices m = start-1 .. end = 0 .. D-1
+    # ---- reference loop body (sample_diffusion.py:201-222)
+    sampler = di.DDIMSampler(m)
+    start_layer, end_layer = torch.where(wholemask.sum((0, 1, 3, 4)))[0][[0, -1]]
+    samples = torch.zeros((n_samples,) + wholemask.shape[1:], dtype=torch.float32)
+    gen_mask = wholemask.repeat(n_samples, 1, 1, 1, 1)
+    it = iter(tape)
+    with mock.patch.object(ut.torch, "randn", lambda *a, **k: next(it)):
+        for m_ in range(start_layer.item() - 1, end_layer.item() + 1):
+            concat_cond = torch.cat([samples[:, :, max(0, m_ - 1)], gen_mask[:, :, m_]], axis=1)
+            c = m.get_learned_conditioning(concat_cond)
+            s, _ = sampler.sample(S=S_steps, dims=len(shape) - 1, conditioning=c, batch_size=n_samples, shape=shape, verbose=False)
+            ds = m.decode_first_stage(s)
+            samples[:, :, m_] = (ds - ds.min()) / (ds.max() - ds.min())
+    assert next(it, None) is None, "the reference consumed fewer draws than the tape holds"
+    # ---- oracle
+    sd_all = sd_of(m)
+    sd_unet, sd_fs, sd_cs = (O.sub_state_dict(sd_all, p) for p in ("model.diffusion_model.", "first_stage_model.", "cond_stage_model."))
+    it2 = iter(tape)
+    mine = S.autoregressive_slices(lambda cc: O.ae_encode_mode(sd_cs, cc),
+                                   lambda c: (lambda x, t: O.unet_forward(sd_unet, torch.cat([x, c], 1), t, model_channels=32, head_channels=32)),
+                                   lambda z: O.ae_decode(sd_fs, z), wholemask, n_samples, shape, lambda shp: next(it2), m.alphas_cumprod, S_steps)
+    per_slice = (mine - samples).abs().flatten(3).max(-1).values[0, 0]
+    print("  autoregressive slices: oracle-vs-reference max|d| per slice:", " ".join(f"{float(v):.1e}" for v in per_slice))
+    close(mine, samples, 2e-4, "autoregressive slice loop")
+    xT = torch.stack(tape[::S_steps + 1])                                                 # the x_T draws (eta = 0: step noises unused)
+    save("autoreg_small", labels=torch.from_numpy(lab).to(torch.uint8), x_T=xT, samples=samples, ddim_steps=np.array(S_steps))
+
+
 def fx_glue():
     """Stage glue: the recipe of latentdiffusion/sample_diffusion.py:199-200,
     rot90(scipy.ndimage.zoom(mask, target / shape, order=0), dims=(1, 2), k=3) / 255, run with scipy itself."""
@@ -613,6 +670,8 @@ if __name__ == "__main__":
         print("text encoder"); fx_text_encoder()
     if "glue" in which or "small" in which or "all" in which:
         print("glue"); fx_glue()
+    if "autoreg" in which or "small" in which or "all" in which:
+        print("autoreg"); fx_autoreg(ldm)
     if "c1" in which or "all" in which:
         fx_e2e(dd, oh, un, ldm, {"c1"})
     if "c2" in which or "all" in which:

