@@ -533,20 +533,20 @@ class DDIMSampler(object):
                 c_concat = conditioning
             elif ck == "crossattn":
                 context = conditioning
-        st = self.prepare_state(N, Cx, sp, dev, c_concat.shape[1] if c_concat is not None else 0)
-        self.load_state(st, x_T, c_concat)
-        ctx_cl = unet.context_cl(context) if context is not None else None
-        self.run_steps(st, ctx_cl, eta, noise_tape)
+        st = self.prepare_state(N, Cx, sp, dev, c_concat.shape[1] if c_concat is not None else 0,
+                                ctx_shape=tuple(context.shape[1:]) if context is not None else None)
+        self.load_state(st, x_T, c_concat, context)
+        self.run_steps(st, st["ctx"], eta, noise_tape)
         perm = (0, nd + 1) + tuple(range(1, nd + 1))
         z = st["x"].view((N,) + sp + (Cx,)).permute(perm).contiguous()
         p0 = st["pred_x0"].view((N,) + sp + (Cx,)).permute(perm).contiguous()
         return z, p0
 
-    def prepare_state(self, N, Cx, sp, dev, Cc):
+    def prepare_state(self, N, Cx, sp, dev, Cc, ctx_shape=None):
         unet = self.model.model.diffusion_model
         sp3 = (1,) * (3 - len(sp)) + tuple(sp)
         S = self.ddim_timesteps.shape[0]
-        key = (N, Cx, sp3, Cc, str(dev))
+        key = (N, Cx, sp3, Cc, str(dev), ctx_shape)
         # everything cached below is a function of the schedule (steps, eta -> sigmas) and of the UNet's weights (time-bias
         # table, packed weights baked into the captured graph): a changed schedule or weight version rebuilds the state
         token = (S, tuple(int(v) for v in self.ddim_timesteps), tuple(float(v) for v in self.ddim_sigmas), ops.weights_token(unet))
@@ -560,12 +560,18 @@ class DDIMSampler(object):
                   pred_x0=torch.empty((N,) + sp3 + (Cx,), dtype=torch.float32, device=dev),
                   unet_in=torch.zeros((N,) + sp3 + (pad32(Cx + Cc),), dtype=torch.bfloat16, device=dev),
                   eps=torch.empty((N,) + sp3 + (pad32(unet.out_channels),), dtype=torch.float32, device=dev),
+                  # cross-attention context [N, L, C] as a STATIC channels-last buffer [N,1,1,L,Cpad]: the captured chain reads it in place
+                  ctx=(CL(torch.zeros((N, 1, 1, ctx_shape[0], pad32(ctx_shape[1])), dtype=torch.bfloat16, device=dev), ctx_shape[1])
+                       if ctx_shape is not None else None),
                   graph=None, warmed=False)
         self._graphs[key] = st
         return st
 
-    def load_state(self, st, x_T: torch.Tensor, c_concat: Optional[torch.Tensor]):
-        """x_T (NC..) -> fp32 CL state + bf16 UNet input; conditioning latent -> channels [Cx, Cx+Cc) of the UNet input."""
+    def load_state(self, st, x_T: torch.Tensor, c_concat: Optional[torch.Tensor], context: Optional[torch.Tensor] = None):
+        """x_T (NC..) -> fp32 CL state + bf16 UNet input; conditioning latent -> channels [Cx, Cx+Cc) of the UNet input; context
+        [N, L, C] -> the state's channels-last context buffer."""
+        if context is not None:
+            ops.to_cl(context.permute(0, 2, 1).contiguous().float(), out=st["ctx"].t, c_offset=0, zero_fill=False)
         nd = x_T.ndim - 2
         perm = (0,) + tuple(range(2, nd + 2)) + (1,)
         st["x"].view((st["N"],) + tuple(x_T.shape[2:]) + (st["Cx"],)).copy_(x_T.permute(perm))        # plumbing: layout copy
@@ -588,7 +594,7 @@ class DDIMSampler(object):
                           pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
 
     def chain_graphable(self, st, ctx_cl=None, eta=0.0, noise_tape=None) -> bool:
-        return bool(self.use_graph and eta == 0.0 and noise_tape is None and ctx_cl is None and st["S"] > 2)
+        return bool(self.use_graph and eta == 0.0 and noise_tape is None and (ctx_cl is None or ctx_cl is st["ctx"]) and st["S"] > 2)
 
     def chain(self, st, ctx_cl=None):
         """All S deterministic steps back to back, every step reading ITS rows of the time-bias / scalar tables in place: no
@@ -601,11 +607,11 @@ class DDIMSampler(object):
         if self.chain_graphable(st, ctx_cl, eta, noise_tape):
             # first call: eager (fills the weight-repack caches); afterwards ONE hipGraph replay per chain
             if not st["warmed"]:
-                self.chain(st)
+                self.chain(st, ctx_cl)
                 st["warmed"] = True
                 return
             if st["graph"] is None:
-                st["graph"] = ops.capture_graph(lambda: self.chain(st))
+                st["graph"] = ops.capture_graph(lambda: self.chain(st, ctx_cl))
             st["graph"].replay()
             return
         for i in range(S):

@@ -219,6 +219,80 @@ def test_c4_full_slice_512_cond_encode_ddim_decode_vs_oracle(dev):
     assert rms_err(n_got, n_ref) < 1.5e-2 and float((n_got - n_ref).abs().max()) < 5e-2
 
 
+# ------------------------------------------------------------------------------------------------ C4 as named: SpatialTransformer
+def test_c4_named_full_size_spatial_transformer_unet_vs_oracle(dev):
+    """BASELINE.json C4 "mask-conditioned SpatialTransformer" at full size: the latent UNet of ..._ae.yaml:17-40 with
+    use_spatial_transformer=True, context_dim=768, transformer_depth=1 (openaimodel.py:467-478,560-562; ldm/modules/attention.py:152-261):
+    365.2 M parameters, N=1, 8x64x64 in, context 512 x 768 (181.5 GFLOP per forward).  (i) one forward vs the oracle,
+    (ii) 5 DDIM steps with hybrid conditioning (c_concat + c_crossattn) vs the oracle's DDIM chain, hipGraph and eager."""
+    from jointimagegeneration_amd.ldm import DDIMSampler, LatentDiffusion
+    from jointimagegeneration_amd.synth import randomize_parameters
+    cfg = dict(LDM_FULL, use_spatial_transformer=True, context_dim=768, transformer_depth=1)
+    m = LatentDiffusion(first_stage_config="__is_no_first_stage__", cond_stage_config=dict(target="ldm.modules.encoders.modules.IdentityEncoder"),
+                        unet_config=dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=cfg), conditioning_key="hybrid",
+                        linear_start=0.0015, linear_end=0.0195, timesteps=1000, image_size=64, channels=4, dims=2, use_ema=False,
+                        first_stage_key="image", cond_stage_key="mask", num_timesteps_cond=1).eval()
+    unet = m.model.diffusion_model
+    randomize_parameters(unet, SEED, "ldm_st.")
+    nparam = sum(p.numel() for p in unet.parameters())
+    assert abs(nparam - 365.2e6) < 0.1e6, nparam                      # BASELINE.md
+    sd = sd_cpu(unet)
+    m = m.to(dev)
+    ge = gen(515)
+    x = torch.randn(1, 8, 64, 64, generator=ge)
+    ctx = torch.randn(1, 512, 768, generator=ge)
+    t = torch.tensor([481])
+    torch.set_num_threads(cores())
+    ref = O.unet_forward(sd, x, t, model_channels=160, head_channels=32, context=ctx)
+    got = unet(x.to(dev), t.to(dev), context=ctx.to(dev))
+    print(f"C4-ST forward (365.2 M params, ctx 512x768): max {rel_err(got, ref):.3e} rms {rms_err(got, ref):.3e}")
+    assert rel_err(got, ref) < 6e-2 and rms_err(got, ref) < 2e-2
+    # (ii) 5 DDIM steps, hybrid conditioning
+    c, x_T = x[:, 4:].contiguous(), torch.randn(1, 4, 64, 64, generator=ge)
+    cond = {"c_concat": [c.to(dev)], "c_crossattn": [ctx.to(dev)]}
+
+    def eps(xx, tt):
+        return O.unet_forward(sd, torch.cat([xx, c], 1), tt, model_channels=160, head_channels=32, context=ctx)
+    ref_z, _ = S.ddim_sample(eps, x_T, [torch.zeros_like(x_T)] * 5, m.alphas_cumprod.cpu(), 5)
+    zs = {}
+    for use_graph in (True, False):
+        smp = DDIMSampler(m)
+        smp.use_graph = use_graph
+        for _ in range(2 if use_graph else 1):                         # second call of a sampler replays the captured 5-step chain
+            z, _ = smp.sample(S=5, batch_size=1, shape=(4, 64, 64), conditioning=cond, verbose=False, x_T=x_T.to(dev), dims=2, eta=0.0)
+        if use_graph:
+            assert next(iter(smp._graphs.values()))["graph"] is not None    # the chain WITH cross-attention context is one hipGraph
+        zs[use_graph] = z
+        print(f"C4-ST 5 DDIM steps (graph={use_graph}): max {rel_err(z, ref_z):.3e} rms {rms_err(z, ref_z):.3e}")
+        assert rel_err(z, ref_z) < 3e-2 and rms_err(z, ref_z) < 1.5e-2
+    assert torch.equal(zs[True], zs[False])
+
+
+# ------------------------------------------------------------------------------------------------ pixel-space shipped config
+PIXEL_UNET = dict(dims=2, image_size=512, in_channels=3, out_channels=1, model_channels=128, attention_resolutions=[32, 16, 8],
+                  num_res_blocks=2, channel_mult=[1, 2, 4, 4, 5], num_head_channels=32)       # ruijin-ldm_from_controlnet.yaml:17-40
+
+
+def test_pixel_space_config_full_size_forward_vs_oracle(dev):
+    """The OTHER shipped LDM config (configs/latent-diffusion/ruijin-ldm_from_controlnet.yaml:17-40): no first stage, IdentityEncoder,
+    UNet directly on 3 x 512 x 512 (x_t | previous slice | mask), 172.9 M parameters, 4.6 TFLOP per forward, attention at 64^2
+    (T = 4096, 16 heads) and 32^2 (T = 1024, 20 heads): one full forward vs the oracle.  A second user of the 2-D halo-tile conv."""
+    from jointimagegeneration_amd.synth import randomize_parameters
+    from jointimagegeneration_amd.unet import UNetModel
+    u = UNetModel(**PIXEL_UNET).eval()
+    randomize_parameters(u, SEED, "ldm_pixel.")
+    assert abs(sum(p.numel() for p in u.parameters()) - 172.9e6) < 0.1e6
+    sd = sd_cpu(u)
+    ge = gen(909)
+    x = torch.randn(1, 3, 512, 512, generator=ge)
+    t = torch.tensor([621])
+    got = u.to(dev)(x.to(dev), t.to(dev)).cpu()
+    torch.set_num_threads(cores())
+    ref = O.unet_forward(sd, x, t, model_channels=128, head_channels=32)
+    print(f"pixel-space UNet forward 3x512^2 (172.9 M params): max {rel_err(got, ref):.3e} rms {rms_err(got, ref):.3e}")
+    assert rel_err(got, ref) < 6e-2 and rms_err(got, ref) < 2e-2
+
+
 # ------------------------------------------------------------------------------------------------ B8: autoregressive slices
 def _slice_errors(got, ref):
     """per-slice (max abs, rms) of [1, D, H, W] volumes in [0, 1]"""
