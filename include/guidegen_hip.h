@@ -262,6 +262,21 @@ int gg_mask_to_cond_slice(const int32_t *labels, int32_t N, int32_t Dm, int32_t 
                           int32_t H, int32_t W, const float *prev, void *cond_cl, int32_t stride, float *mask_out,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp32 VALIDATION mode of the CCDM path (gg_f32.hip): the same network functions on fp32 channels-last tensors with fp32 weights
+ * and fp32 FMA accumulation in a fixed order, so that integer outputs (labels) can be compared exactly with the fp32 CPU
+ * reference (the reference's own precision switch: ccdm/ddpm/models/unet_openai/unet.py:447,742-756).  Not a fast path.
+ * ------------------------------------------------------------------------------------------------ */
+/* gg_conv_desc with fp32 tensors: src1 / src2 / residual / out are fp32 CL, out_dtype must be GG_F32, `weight` is fp32
+ * [taps][C1+C2][Cout_pad] (tap-major, zero padded), bias as in gg_conv_forward; prologue_act, gn_acc, ddim_x, epilogue_geglu must be 0. */
+int gg_conv_forward_f32(const gg_conv_desc *desc, void *stream);
+/* act(GroupNorm(32)(cat[src1, src2])) on fp32 CL tensors: statistics in fp64, (x - mean) * rstd * gamma + beta in fp32 (ATen's
+ * order), act 1 = SiLU with an IEEE division.  out fp32 CL [N, S, C1+C2] (pad lanes zero); workspace: 64 * N floats. */
+int gg_groupnorm_f32(const float *src1, int32_t C1, const float *src2, int32_t C2, int32_t N, int64_t S, int32_t C_logical,
+                     const float *gamma, const float *beta, float eps, int32_t act, float *out, float *workspace, void *stream);
+/* gg_attention_desc with fp32 q / k / v / out (head_dim <= 64): softmax((q a)(k a)^T) v, a = sqrt(scale), all fp32. */
+int gg_attention_forward_f32(const gg_attention_desc *desc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

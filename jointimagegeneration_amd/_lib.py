@@ -70,6 +70,9 @@ SIGNATURES = {
     "gg_minmax_normalise": (C.c_int, [vp, i64, vp, vp, vp]),
     "gg_ddpm_step": (C.c_int, [vp, vp, i32, vp, vp, i64, i32, vp, i32, vp]),
     "gg_lincomb4": (C.c_int, [vp, vp, vp, vp, f32, f32, f32, f32, f32, i64, vp, vp]),
+    "gg_conv_forward_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "gg_groupnorm_f32": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, i32, vp, vp, vp]),
+    "gg_attention_forward_f32": (C.c_int, [C.POINTER(AttentionDesc), vp]),
     "gg_mask_to_cond_slice": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
 }
 

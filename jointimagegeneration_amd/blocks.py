@@ -69,7 +69,7 @@ def packed_conv(mod: nn.Module, cin_pad: int, tag: str = ""):
         pw = ops.pack_conv_weight(w, cin_pad)
         pb = ops.pad_bias(getattr(mod, "bias", None), w.shape[0], w.device)
         return pw, pb
-    return PACKED.get((id(mod), cin_pad, tag), [mod.weight, getattr(mod, "bias", None)], build)
+    return PACKED.get((id(mod), cin_pad, tag, ops.FP32), [mod.weight, getattr(mod, "bias", None)], build)
 
 
 def packed_cat(mods: List[nn.Module], cin_pad: int, tag: str):
@@ -83,7 +83,7 @@ def packed_cat(mods: List[nn.Module], cin_pad: int, tag: str):
         pb = ops.pad_bias(torch.cat(bs, 0), w.shape[0], w.device)
         return pw, pb
     params = [m.weight for m in mods] + [getattr(m, "bias", None) for m in mods]
-    return PACKED.get((id(mods[0]), cin_pad, tag), params, build)
+    return PACKED.get((id(mods[0]), cin_pad, tag, ops.FP32), params, build)
 
 
 def packed_geglu(proj: nn.Module, cin_pad: int):
@@ -109,6 +109,8 @@ def f32(p: torch.Tensor) -> torch.Tensor:
 
 
 def gn_silu(h: CL, norm: nn.GroupNorm, act: bool, src2: Optional[CL] = None) -> CL:
+    if ops.is_f32(h.t):                      # fp32 validation path
+        return ops.groupnorm_f32(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
     if ops.groupnorm_fused_ok(h, src2):     # small tensor: statistics + apply in one launch
         return ops.groupnorm_fused(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
     if ops.has_stats(h, src2):      # the producing convs already left the per-channel sums: no statistics launch
@@ -122,6 +124,8 @@ def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Op
     Halo-tile convs (3x3(x3), stride 1, large extents): one stats pass, then normalise*affine(+SiLU) and the skip concat are
     fused into the conv's staging pass (applied once per staged element) -- the activation is never re-written to HBM.
     Gather-kernel convs: separate apply pass (measured: SiLU inside the latency-bound gather loop costs 26 vs 16.6 us/conv)."""
+    if ops.is_f32(h.t):                      # fp32 validation path: separate fp32 GroupNorm launch, then the fp32 conv
+        return ops.conv(ops.groupnorm_f32(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2), weight, bias, cout, **conv_kw)
     fused = ops.conv_fuses_prologue(h, cout, src2=src2, **conv_kw)
     if not fused and ops.groupnorm_fused_ok(h, src2):     # small tensor: statistics + apply in ONE launch
         a = ops.groupnorm_fused(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
@@ -247,7 +251,7 @@ class AttentionBlock(nn.Module):
         N, T = h.N, h.S
         pw, pb = packed_conv(self.qkv, h.Cpad)
         qkv = norm_conv(h, self.norm, False, pw, pb, 3 * Cc, k=(1, 1, 1), pad=0)   # legacy order: head-major, q|k|v per head
-        att = torch.empty(tuple(h.t.shape[:4]) + (Cc,), dtype=torch.bfloat16, device=h.t.device)
+        att = torch.empty(tuple(h.t.shape[:4]) + (Cc,), dtype=h.t.dtype, device=h.t.device)
         ld = qkv.Cpad
         ops.attention(qkv.t, qkv.t, qkv.t, att, N, nh, ch, T, T, (ld, 3 * ch), (ld, 3 * ch), (ld, 3 * ch), (Cc, ch),
                       1.0 / math.sqrt(ch), q_off=0, k_off=ch, v_off=2 * ch)

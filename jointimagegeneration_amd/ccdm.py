@@ -159,7 +159,7 @@ class DenoisingModel(nn.Module):
         scal = self.diffusion.step_scalars(tv).to(dev)
         table = unet.time_bias_table(torch.tensor(tv, dtype=torch.float32, device=dev), N)
         cin = unet.in_channels
-        xin = torch.zeros((N,) + sp3 + (pad32(cin),), dtype=torch.bfloat16, device=dev)
+        xin = torch.zeros((N,) + sp3 + (pad32(cin),), dtype=torch.float32 if ops.FP32 else torch.bfloat16, device=dev)
         lab = labels.contiguous().view(-1).clone()
         ops.labels_to_onehot(lab, K, xin.view(M, -1))                 # channels [0,K) one-hot, rest zero
         if condition is not None:                                     # unet.py:774-775: cat([x, input_condition], 1)
@@ -173,11 +173,14 @@ class DenoisingModel(nn.Module):
 
         def step(draw: bool, E=None, want_probs=False):
             unet.forward_cl(xcl, cur_bias, head_out=logits)
+            bf16_in = xin.dtype == torch.bfloat16
             ops.ccdm_posterior_sample(logits.view(M, -1), True, lab, cur_scal, K, E=E, philox_seed=self.philox_seed,
                                       philox_offset=cur_off, draw=draw, labels_out=lab,
-                                      probs_out=probs if want_probs else None, onehot_out=xin.view(M, -1))
+                                      probs_out=probs if want_probs else None, onehot_out=xin.view(M, -1) if bf16_in else None)
+            if not bf16_in:                                           # fp32 validation mode: the one-hot input is refreshed by an index scatter
+                ops.labels_to_onehot(lab, K, xin.view(M, -1))
 
-        use_graph = self.use_graph and rng_tapes is None and trace is None and S > 3
+        use_graph = self.use_graph and rng_tapes is None and trace is None and S > 3 and not ops.FP32
         graph, warmed, ti = None, False, 0
         for i, t in enumerate(tv):
             cur_bias.copy_(table[i]); cur_scal.copy_(scal[i]); cur_off.fill_(t)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -fno-gpu-rdc"
 OBJS=()
-for f in gg_conv gg_conv_halo gg_conv_box gg_conv_tiny gg_norm gg_attn gg_sampler; do
+for f in gg_conv gg_conv_halo gg_conv_box gg_conv_tiny gg_norm gg_attn gg_sampler gg_f32; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gg_common.h -nt $f.o ] || [ gg_conv.h -nt $f.o ] || [ ../../include/guidegen_hip.h -nt $f.o ]; then
     echo "hipcc $f.hip"
     EXTRA=""

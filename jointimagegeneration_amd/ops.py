@@ -33,6 +33,29 @@ def require_gpu(t: torch.Tensor, what: str) -> None:
                            "(no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")
 
 
+# fp32 VALIDATION mode (gg_f32.hip; include/guidegen_hip.h): inside `with ops.fp32_validation():` the layout movers create fp32
+# channels-last tensors and fp32 [taps][Cin][Cout] weight packs, and every op below routes fp32 tensors to the fp32 kernels (fixed-order
+# fp32 FMA accumulation, fp64 GroupNorm statistics, fp32 attention).  It exists so that the CCDM sampler's labels can be compared exactly
+# with the fp32 reference; nothing on the production path is changed by it, and there is still no CPU path.
+FP32 = False
+
+
+class fp32_validation:
+    def __enter__(self):
+        global FP32
+        self.prev, FP32 = FP32, True
+        return self
+
+    def __exit__(self, *exc):
+        global FP32
+        FP32 = self.prev
+        return False
+
+
+def is_f32(t) -> bool:
+    return t.dtype == torch.float32
+
+
 PATH_HINT = 0        # gg_conv_desc.path_hint: tests set 1 / 4 / 6 to run small shapes on the halo-tile kernel (production: 0)
 def weights_token(module) -> Tuple[int, int, int]:
     """Cheap identity of a module's current weights: (#tensors, sum of in-place version counters, sum of storage addresses).
@@ -107,6 +130,13 @@ def to_cl(x: torch.Tensor, c_pad: Optional[int] = None, out: Optional[torch.Tens
     sp = tuple(x.shape[2:])
     sp3 = (1,) * (3 - len(sp)) + sp
     S = sp3[0] * sp3[1] * sp3[2]
+    if (out is None and FP32) or (out is not None and is_f32(out)):      # validation mode: fp32 channels-last (layout copy = plumbing)
+        if out is None:
+            out = torch.zeros((N,) + sp3 + (c_pad or pad32(Cc + c_offset),), dtype=torch.float32, device=x.device)
+        elif zero_fill:
+            out.zero_()
+        out[..., c_offset:c_offset + Cc] = x.reshape(N, Cc, S).permute(0, 2, 1).reshape((N,) + sp3 + (Cc,))
+        return CL(out, Cc + c_offset)
     if out is None:
         cp = c_pad or pad32(Cc + c_offset)
         out = torch.empty((N,) + sp3 + (cp,), dtype=torch.bfloat16, device=x.device)
@@ -135,6 +165,11 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
     lib = _lib.load()
     w = w.detach().contiguous().float()
     Cout, Cin = w.shape[:2]
+    if FP32:                                     # validation mode: fp32 [taps][Cin_pad][Cout_pad], zero padded (layout copy = plumbing)
+        wt = w.reshape(Cout, Cin, -1).permute(2, 1, 0)
+        out = torch.zeros((wt.shape[0], cin_pad, pad32(Cout)), dtype=torch.float32, device=w.device)
+        out[:, :Cin, :Cout] = wt
+        return out
     ntaps = 1
     for s in w.shape[2:]:
         ntaps *= s
@@ -168,6 +203,8 @@ def conv_out_extent(in_sp: Sequence[int], k: Sequence[int], stride: int, pad: in
 def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
                         src2: Optional[CL] = None, **_ignored) -> bool:
     """True if this conv runs on the halo-tile kernel (GroupNorm prologue applied once per element while staging)."""
+    if is_f32(src1.t):
+        return False
     lib = _lib.load()
     N, D, H, W, C1 = src1.t.shape
     Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
@@ -232,6 +269,25 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     N, D, H, W, C1 = t1.shape
     Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
     cp = pad32(cout)
+    if is_f32(t1):                                  # fp32 validation path (gg_conv_forward_f32)
+        if geglu or prologue is not None or not is_f32(weight) or (residual is not None and not is_f32(residual.t)):
+            raise RuntimeError("fp32 validation conv: fp32 weights / residual, no fused prologue or GEGLU (enter ops.fp32_validation() before the first forward)")
+        if out is None:
+            out = torch.empty((N, Do, Ho, Wo, cp), dtype=torch.float32, device=t1.device)
+        d = ConvDesc()
+        d.N, d.D, d.H, d.W = N, D, H, W
+        d.C1, d.C2 = C1, (src2.t.shape[-1] if src2 is not None else 0)
+        d.Cout, d.Cout_pad = cout, cp
+        d.kd, d.kh, d.kw = k
+        d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+        d.Do, d.Ho, d.Wo = Do, Ho, Wo
+        d.out_dtype = GG_F32
+        d.src1, d.src2 = t1.data_ptr(), (_ptr(src2.t) if src2 is not None else None)
+        d.weight, d.bias, d.bias_stride = weight.data_ptr(), _ptr(bias), (cp if bias_per_sample else 0)
+        d.residual = _ptr(residual.t) if residual is not None else None
+        d.out = out.data_ptr()
+        check(lib.gg_conv_forward_f32(C.byref(d), _stream()), "gg_conv_forward_f32")
+        return CL(out, cout)
     if geglu:      # fused GEGLU epilogue (gg_conv_desc.epilogue_geglu): cout = 2 * inner value | gate rows in, inner channels out
         if cout % 32 or out is not None or out_f32 or residual is not None:
             raise ValueError("conv(geglu=True): cout = 2 * inner with inner % 16 == 0, bf16 output, no residual")
@@ -316,6 +372,8 @@ def groupnorm_apply(src1: CL, scale: torch.Tensor, shift: torch.Tensor, act: boo
 
 
 def groupnorm_fused_ok(src1: CL, src2: Optional[CL] = None) -> bool:
+    if is_f32(src1.t):
+        return False
     C2 = src2.Cpad if src2 is not None else 0
     c_log = src1.C + (src2.C if src2 is not None else 0)
     if src2 is not None and src1.C != src1.Cpad:
@@ -333,6 +391,22 @@ def groupnorm_fused(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: floa
     out = torch.empty(tuple(src1.t.shape[:4]) + (C1 + C2,), dtype=torch.bfloat16, device=src1.t.device)
     check(lib.gg_groupnorm_fused(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, c_log, gamma.data_ptr(),
                                  beta.data_ptr(), eps, 1 if act else 0, out.data_ptr(), _stream()), "gg_groupnorm_fused")
+    return CL(out, c_log)
+
+
+def groupnorm_f32(src1: CL, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: bool, src2: Optional[CL] = None) -> CL:
+    """fp32 validation path: act(GroupNorm(32)(cat[src1, src2])) on fp32 CL tensors (fp64 statistics, ATen's fp32 affine order)."""
+    lib = _lib.load()
+    N, S = src1.N, src1.S
+    C1 = src1.Cpad
+    C2 = src2.Cpad if src2 is not None else 0
+    c_log = src1.C + (src2.C if src2 is not None else 0)
+    if src2 is not None and src1.C != C1:
+        raise RuntimeError("two-source GroupNorm needs an unpadded first source")
+    out = torch.empty(tuple(src1.t.shape[:4]) + (C1 + C2,), dtype=torch.float32, device=src1.t.device)
+    ws = torch.empty(64 * N, dtype=torch.float32, device=src1.t.device)
+    check(lib.gg_groupnorm_f32(src1.t.data_ptr(), C1, _ptr(src2.t) if src2 is not None else None, C2, N, S, c_log, gamma.data_ptr(), beta.data_ptr(),
+                               eps, 1 if act else 0, out.data_ptr(), ws.data_ptr(), _stream()), "gg_groupnorm_f32")
     return CL(out, c_log)
 
 
@@ -416,10 +490,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.ldv, d.hsv = ld_hs_v
     d.ldo, d.hso = ld_hs_o
     d.scale = scale
-    d.q = q.data_ptr() + 2 * q_off
-    d.k = k.data_ptr() + 2 * k_off
-    d.v = v.data_ptr() + 2 * v_off
+    esz = q.element_size()
+    d.q = q.data_ptr() + esz * q_off
+    d.k = k.data_ptr() + esz * k_off
+    d.v = v.data_ptr() + esz * v_off
     d.out = out.data_ptr()
+    if is_f32(q):                                   # fp32 validation path
+        check(lib.gg_attention_forward_f32(C.byref(d), _stream()), "gg_attention_forward_f32")
+        return
     check(lib.gg_attention_forward(C.byref(d), _stream()), "gg_attention_forward")
 
 
@@ -465,6 +543,9 @@ def ccdm_posterior_sample(head: torch.Tensor, head_is_logits: bool, xt: torch.Te
 
 def labels_to_onehot(labels: torch.Tensor, K: int, out: torch.Tensor) -> None:
     lib = _lib.load()
+    if is_f32(out):                                 # fp32 validation path: index scatter (plumbing)
+        out[:, :K] = torch.nn.functional.one_hot(labels.long(), K).to(torch.float32)
+        return
     check(lib.gg_labels_to_onehot(labels.data_ptr(), labels.numel(), K, out.data_ptr(), out.shape[-1], _stream()), "gg_labels_to_onehot")
 
 

@@ -151,6 +151,70 @@ def test_c1_full_ccdm_32_teacher_forced_vs_reference_fixture(dev):
     assert tv < 0.05          # measured 0.014
 
 
+def test_c1_fp32_validation_mode_labels_bit_exact(dev):
+    """north_star "bit-exact for the argmax mask labels" / SURVEY section 7 hard part 1 (ii): the full-size CCDM UNet (95.4 M params) at
+    32^3 in the engine's fp32 VALIDATION mode (gg_f32.hip: fp32 channels-last activations, fp32 weights, fixed-order fp32 FMA, fp64
+    GroupNorm statistics; the posterior / race kernel is the production one).  Teacher-forced on the REFERENCE's recorded states
+    with the reference's exponential tapes at t = 50, 49, 26, 2, 1: every label equal, 0 mismatches allowed."""
+    from jointimagegeneration_amd import ops
+    g = gold("e2e_c1")
+    with ops.fp32_validation():
+        model, sd, K = _full_ccdm(dev, 50)
+        R, M, Tn = 32, 32 ** 3, 50
+        ge = gen(SEED)
+        torch.empty(M, K).exponential_(1, generator=ge)                                      # E0 (x_T draw) precedes the step tapes
+        tapes = [torch.empty(M, K).exponential_(1, generator=ge) for _ in range(Tn - 1)]
+        cond = torch.zeros(1, 1, R, R, R)
+        step_t, step_in, step_out = [int(v) for v in g["step_t"]], T(g["step_in"]).int(), T(g["step_out"]).int()
+        xt = S.one_hot_bchw(step_in[0][None].long(), K)
+        torch.set_num_threads(cores())
+        ref_p = O.unet_forward(sd, torch.cat([xt, cond], 1), torch.tensor([50.0]), model_channels=64, head_channels=32, softmax_out=True)
+        got_p = model.unet(xt.to(dev), cond.to(dev), None, torch.tensor([50.0], device=dev))["diffusion_out"].cpu()
+        d = (got_p - ref_p).abs()
+        print(f"C1 fp32 validation mode, forward @32^3: probs max abs err {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
+        assert float(d.max()) < 2e-5
+        total = 0
+        for j, t in enumerate(step_t):
+            trace = []
+            model.sample_labels(step_in[j][None].to(dev), cond.to(dev), init_t=t, rng_tapes=tapes[Tn - t:], trace=trace)
+            mism = int((trace[0]["labels"].cpu()[0] != step_out[j]).sum())
+            print(f"C1 fp32 validation mode, teacher-forced step t={t}: {mism} / {M} label mismatches vs the reference")
+            total += mism
+        assert total == 0
+
+
+def test_c1_bf16_peaked_posteriors_label_flips(dev):
+    """random head weights give near-uniform posteriors (the worst case for label agreement).  With the head conv
+    scaled so that > 90 % of the voxels have an oracle top-2 margin > 0.1 (what a trained network produces), the bf16 production
+    engine's labels vs the fp32 oracle: sampled step (t = 26, exponential tape) and final argmax (t = 1).  Bound: <= 0.1 % flips."""
+    model, sd, K = _full_ccdm(dev, 50)
+    R, M, Tn = 32, 32 ** 3, 50
+    scale = 40.0
+    with torch.no_grad():
+        model.unet.out[2].weight.mul_(scale); model.unet.out[2].bias.mul_(scale)          # in-place: version bump => repack
+    sd = dict(sd)
+    sd["out.2.weight"], sd["out.2.bias"] = sd["out.2.weight"] * scale, sd["out.2.bias"] * scale
+    ge = gen(99)
+    lab = torch.from_numpy(synth_labels((R, R, R), K, seed=3))[None]
+    cond = torch.zeros(1, 1, R, R, R)
+    torch.set_num_threads(cores())
+    _, al, ca = S.ccdm_schedule("cosine", Tn)
+    for t in (26, 1):
+        E = torch.empty(M, K).exponential_(1, generator=ge)
+        xt = S.one_hot_bchw(lab, K)
+        p0 = O.unet_forward(sd, torch.cat([xt, cond], 1), torch.tensor([float(t)]), model_channels=64, head_channels=32, softmax_out=True)
+        top2 = p0.topk(2, dim=1).values
+        peaked = float(((top2[:, 0] - top2[:, 1]) > 0.1).float().mean())
+        a, abar = S.ccdm_step_scalars(al, ca, t)
+        post = torch.clamp(S.theta_post_prob(xt, p0, a, abar), min=1e-12)
+        want = S.race_sample_labels(post, E) if t > 1 else (post / post.sum(1, keepdim=True)).argmax(1)
+        trace = []
+        model.sample_labels(lab.int().to(dev), cond.to(dev), init_t=t, rng_tapes=[E], trace=trace)
+        mism = int((trace[0]["labels"].cpu() != want).sum())
+        print(f"C1 bf16, peaked posteriors (head x{scale:g}: {peaked:.3f} of voxels with p0 margin > 0.1), step t={t}: {mism} / {M} label flips vs the oracle")
+        assert peaked > 0.9 and mism <= 1e-3 * M
+
+
 # ------------------------------------------------------------------------------------------------ C3
 def test_c3_full_ccdm_128_forward_vs_oracle(dev):
     """Config C3: ONE full 128^3 forward of the 95 M-param CCDM UNet (12.7 TFLOP) under the production dispatch, vs the CPU oracle

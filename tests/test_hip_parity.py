@@ -994,3 +994,61 @@ def test_full_size_posterior_properties(dev):
     assert torch.allclose(probs.sum(-1), torch.ones(M, device=dev), atol=1e-5)
     freq = torch.bincount(a.long(), minlength=K).float() / M
     assert float((freq - probs.mean(0)).abs().max()) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ fp32 validation kernels
+def test_fp32_validation_kernels_vs_torch(dev):
+    """gg_f32.hip (fp32 validation mode of the CCDM path) against ATen fp32 on the CPU: 3-D convs (3x3x3 stride 1 / 2, fused x2
+    upsample, 1x1x1, skip concat as second source, per-sample bias, residual, channel padding), GroupNorm(+SiLU) with one and two
+    sources, QKVAttentionLegacy.  Tolerance: a few fp32 ulps of the output scale (different summation orders only)."""
+    import torch.nn.functional as F
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(4242)
+    tol = 3e-6
+    with ops.fp32_validation():
+        x = torch.randn(2, 15, 6, 8, 10, generator=g)
+        x2 = torch.randn(2, 64, 6, 8, 10, generator=g)
+        xcl, x2cl = ops.to_cl(x.to(dev)), ops.to_cl(x2.to(dev))
+        assert xcl.t.dtype == torch.float32 and xcl.Cpad == 32
+        for (cout, k, stride, up) in ((40, 3, 1, False), (64, 3, 2, False), (33, 3, 1, True), (96, 1, 1, False)):
+            w = torch.randn(cout, 15, k, k, k, generator=g) / math.sqrt(15 * k ** 3)
+            b = torch.randn(2, cout, generator=g)
+            xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+            ref = F.conv3d(xin, w, None, stride=stride, padding=k // 2) + b[:, :, None, None, None]
+            bias = torch.zeros(2, ops.pad32(cout)); bias[:, :cout] = b
+            got = ops.conv(xcl, ops.pack_conv_weight(w.to(dev), 32), bias.to(dev), cout, k=(k, k, k), stride=stride, pad=k // 2, upsample=up,
+                           bias_per_sample=True)
+            assert got.t.dtype == torch.float32 and float(got.t[..., cout:].abs().max() if got.Cpad > cout else 0.0) == 0.0
+            assert rel_err(ops.from_cl(got, 3), ref) < tol, (cout, k, stride, up)
+        # skip concat (second source) + residual
+        w = torch.randn(64, 64 + 64, 3, 3, 3, generator=g) / math.sqrt(128 * 27)
+        res = torch.randn(2, 64, 6, 8, 10, generator=g)
+        x1 = torch.randn(2, 64, 6, 8, 10, generator=g)
+        ref = F.conv3d(torch.cat([x1, x2], 1), w, None, padding=1) + res
+        got = ops.conv(ops.to_cl(x1.to(dev)), ops.pack_conv_weight(w.to(dev), 128), None, 64, k=(3, 3, 3), src2=x2cl, residual=ops.to_cl(res.to(dev)))
+        assert rel_err(ops.from_cl(got, 3), ref) < tol
+        # GroupNorm (+SiLU), one source with an offset mean, and the two-source concat (groups straddle the boundary: 96 + 64 = 160 / 32 = 5)
+        xa = torch.randn(2, 96, 4, 6, 6, generator=g) * 1.5 + 3.0
+        xb = torch.randn(2, 64, 4, 6, 6, generator=g)
+        gam, bet = 1 + 0.1 * torch.randn(160, generator=g), 0.1 * torch.randn(160, generator=g)
+        for act in (True, False):
+            ref = F.group_norm(xa, 32, gam[:96], bet[:96], 1e-5)
+            ref = F.silu(ref) if act else ref
+            got = ops.groupnorm_f32(ops.to_cl(xa.to(dev)), gam[:96].contiguous().to(dev), bet[:96].contiguous().to(dev), 1e-5, act)
+            assert rel_err(ops.from_cl(got, 3), ref) < tol
+            ref = F.group_norm(torch.cat([xa, xb], 1), 32, gam, bet, 1e-5)
+            ref = F.silu(ref) if act else ref
+            got = ops.groupnorm_f32(ops.to_cl(xa.to(dev)), gam.to(dev), bet.to(dev), 1e-5, act, src2=ops.to_cl(xb.to(dev)))
+            assert rel_err(ops.from_cl(got, 3), ref) < tol
+        # AttentionBlock (legacy qkv order) as a whole module, fp32
+        from jointimagegeneration_amd.blocks import AttentionBlock
+        ab = seeded(AttentionBlock(64, num_heads=1, num_head_channels=32), "ab3d.")
+        gm = gold("modules")
+        ref = T(gm["ab3d_y"])
+        got = ab.to(dev).run(ops.to_cl(T(gm["ab3d_x"]).to(dev)))
+        assert got.t.dtype == torch.float32
+        e = rel_err(ops.from_cl(got, 3), ref)
+        print(f"fp32 validation AttentionBlock vs the reference fixture: {e:.2e}")
+        assert e < 1e-5
+    # leaving the mode: the production (bf16) packs are used again
+    assert ops.to_cl(x.to(dev)).t.dtype == torch.bfloat16
