@@ -209,7 +209,7 @@ def test_c1_bf16_peaked_posteriors_label_flips(dev):
         post = torch.clamp(S.theta_post_prob(xt, p0, a, abar), min=1e-12)
         want = S.race_sample_labels(post, E) if t > 1 else (post / post.sum(1, keepdim=True)).argmax(1)
         trace = []
-        model.sample_labels(lab.int().to(dev), cond.to(dev), init_t=t, rng_tapes=[E], trace=trace)
+        model.sample_labels(lab.int().to(dev), cond.to(dev), init_t=t, rng_tapes=[E] * t, trace=trace)      # the chain runs on to t = 1; trace[0] is step t
         mism = int((trace[0]["labels"].cpu() != want).sum())
         print(f"C1 bf16, peaked posteriors (head x{scale:g}: {peaked:.3f} of voxels with p0 margin > 0.1), step t={t}: {mism} / {M} label flips vs the oracle")
         assert peaked > 0.9 and mism <= 1e-3 * M
