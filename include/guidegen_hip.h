@@ -105,6 +105,18 @@ typedef struct {
      * (acc_value + bias_value)[j] * gelu_erf((acc_gate + bias_gate)[j]) from the fp32 accumulators, row stride Cout_pad / 2.
      * 0 = plain conv. */
     int32_t epilogue_geglu;
+    /* Optional GroupNorm prologue computed FROM ACCUMULATORS inside the conv (no statistics launch, no scale / shift launch, no apply
+     * launch): with prologue_act != 0, gn_scale == gn_shift == NULL and pro_acc1 != NULL, every workgroup folds the per-channel
+     * fixed-point (sum, sumsq) accumulators the PRODUCING convs left for src1 / src2 (the 1-stripe layout [N][1][C][2] of
+     * gg_conv_desc.gn_acc, i.e. producers with gg_conv_emits_stats == 1) into the GroupNorm(32) scale / shift table in LDS and applies
+     * normalise * affine (* SiLU) in place to its staged input box.  Only where gg_conv_prologue_from_acc(desc) == 1 (box kernel:
+     * affine-only norms always, SiLU norms where few cout tiles share a box or the image is tiny). */
+    int32_t pro_c_logical;       /* logical channels of cat[src1, src2] (multiple of 32 groups)            */
+    const int64_t *pro_acc1;     /* [N][1][C1][2]                                                          */
+    const int64_t *pro_acc2;     /* [N][1][C2][2] or NULL (C2 == 0)                                        */
+    const float *pro_gamma;      /* fp32 [pro_c_logical]                                                   */
+    const float *pro_beta;
+    float pro_eps;
     int32_t reserved_tail;
 } gg_conv_desc;
 
@@ -123,6 +135,9 @@ int gg_conv_fuses_prologue(const gg_conv_desc *desc);
 /* 0 if gg_conv_forward(desc) will not fill desc->gn_acc, else the number of stripes S of the [N][S][Cout_pad][2] accumulator it fills
  * (1 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
 int gg_conv_emits_stats(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) can compute the GroupNorm prologue desc->prologue_act from accumulators (gg_conv_desc.pro_acc1) on its
+ * own; pointers are not read. */
+int gg_conv_prologue_from_acc(const gg_conv_desc *desc);
 /* 1 if gg_conv_forward(desc) can run the fused DDIM epilogue (see gg_conv_desc.ddim_x); pointers are not read. */
 int gg_conv_fuses_ddim(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);

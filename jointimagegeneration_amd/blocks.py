@@ -126,6 +126,9 @@ def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Op
     Gather-kernel convs: separate apply pass (measured: SiLU inside the latency-bound gather loop costs 26 vs 16.6 us/conv)."""
     if ops.is_f32(h.t):                      # fp32 validation path: separate fp32 GroupNorm launch, then the fp32 conv
         return ops.conv(ops.groupnorm_f32(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2), weight, bias, cout, **conv_kw)
+    if ops.conv_prologue_from_acc(h, cout, act, src2=src2, **conv_kw):
+        # box conv + producers' sums: the conv folds them and normalises its staged box itself -- NO GroupNorm launch of any kind
+        return ops.conv(h, weight, bias, cout, src2=src2, prologue_acc=(f32(norm.weight), f32(norm.bias), norm.eps), prologue_silu=act, **conv_kw)
     fused = ops.conv_fuses_prologue(h, cout, src2=src2, **conv_kw)
     if not fused and ops.groupnorm_fused_ok(h, src2):     # small tensor: statistics + apply in ONE launch
         a = ops.groupnorm_fused(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
@@ -210,7 +213,9 @@ class ResBlock(TimestepBlock):
         b = PACKED.get((id(self), "tb"), [lin.bias, c1.bias], lambda: (f32(lin.bias) + f32(c1.bias)))
         ops.linear_f32(emb, f32(lin.weight), b, act_in=True, out=out)
 
-    def run(self, h: CL, tbias: torch.Tensor, src2: Optional[CL] = None) -> CL:
+    def run(self, h: CL, tbias: torch.Tensor, src2: Optional[CL] = None, want_stats: bool = False) -> CL:
+        """want_stats: the consumer of this block's output folds GroupNorm sums itself (an AttentionBlock's norm in front of its box-kernel
+        qkv conv, or a tiny-image ResBlock): conv2 leaves them even for tensors below ops.GN_ACC_MIN_ELEMS."""
         c1, c2 = self.in_layers[2], self.out_layers[3]
         k = _k3(c1.weight)
         cin_pad = h.Cpad + (src2.Cpad if src2 is not None else 0)
@@ -224,7 +229,7 @@ class ResBlock(TimestepBlock):
         pw1, _ = packed_conv(c1, cin_pad)
         h1 = norm_conv(h, self.in_layers[0], True, pw1, tbias, self.out_channels, src2=src2, k=k, bias_per_sample=True)
         pw2, pb2 = packed_conv(c2, h1.Cpad)
-        return norm_conv(h1, self.out_layers[0], True, pw2, pb2, self.out_channels, k=k, residual=res)
+        return norm_conv(h1, self.out_layers[0], True, pw2, pb2, self.out_channels, k=k, residual=res, want_stats=want_stats)
 
 
 class AttentionBlock(nn.Module):
@@ -365,9 +370,12 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Dispatches (h, time-bias, context, skip) to the children that take them (unet.py:70-84)."""
 
     def run(self, h: CL, tbias_of, context: Optional[CL], skip: Optional[CL] = None) -> CL:
-        for layer in self:
+        layers = list(self)
+        for i, layer in enumerate(layers):
             if isinstance(layer, ResBlock):
-                h = layer.run(h, tbias_of(layer), skip)
+                # the next layer's norm can be folded into its (box-kernel) conv from this block's output sums
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                h = layer.run(h, tbias_of(layer), skip, want_stats=isinstance(nxt, (AttentionBlock, SpatialTransformer)))
                 skip = None
             elif isinstance(layer, SpatialTransformer):
                 h = layer.run(h, context)

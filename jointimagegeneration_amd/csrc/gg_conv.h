@@ -23,6 +23,11 @@ struct ConvParams {
     // multiply-high magics (gg_fastdiv) of the output-position decode m -> (n, od, oh, ow); 0 where M * divisor >= 2^32
     unsigned mg_osp, mg_ohw, mg_wo;
     int epi_geglu;            // gg_conv_desc.epilogue_geglu (generic gather kernel without split-K only)
+    // GroupNorm prologue from accumulators (gg_conv_desc.pro_acc1; box kernel only)
+    const long long *pro_acc1, *pro_acc2;
+    const float *pro_gamma, *pro_beta;
+    float pro_eps;
+    int pro_clog;
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

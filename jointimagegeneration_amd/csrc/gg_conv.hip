@@ -699,6 +699,9 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.ddim_x = d->ddim_x; p.ddim_pred_x0 = d->ddim_pred_x0; p.ddim_scalars = d->ddim_scalars;
     p.ddim_unet_in = (bf16_t *)d->ddim_unet_in; p.ddim_unet_in_stride = d->ddim_unet_in_stride;
     p.epi_geglu = d->epilogue_geglu;
+    p.pro_acc1 = (const long long *)d->pro_acc1; p.pro_acc2 = (const long long *)d->pro_acc2; p.pro_gamma = d->pro_gamma; p.pro_beta = d->pro_beta;
+    p.pro_eps = d->pro_eps; p.pro_clog = d->pro_c_logical;
+    if (d->gn_scale || d->gn_shift || !d->prologue_act) p.pro_acc1 = p.pro_acc2 = nullptr;          // external tables win; no prologue: unused
     p.mg_osp = gg_magic_u32(p.M, d->Do * d->Ho * d->Wo); p.mg_ohw = gg_magic_u32(p.M, d->Ho * d->Wo); p.mg_wo = gg_magic_u32(p.M, d->Wo);
 }
 
@@ -717,6 +720,17 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 }
 
 bool gg_conv_box_emits_stats(const ConvParams &p);
+bool gg_conv_box_prologue_from_acc(const ConvParams &p);
+
+extern "C" int gg_conv_prologue_from_acc(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu || !d->prologue_act) return 0;
+    if (d->pro_c_logical <= 0 || d->pro_c_logical % 32 || d->pro_c_logical > d->C1 + d->C2 || (d->C2 && d->pro_c_logical < d->C1)) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    if (halo_try_dry(p)) return 0;
+    return gg_conv_box_try(p, (hipStream_t)-1) == GG_OK && gg_conv_box_prologue_from_acc(p) ? 1 : 0;
+}
 
 // The fused DDIM epilogue lives in the box kernel's epilogue (the latent UNet's head conv at batch 1..4 runs there).
 extern "C" int gg_conv_fuses_ddim(const gg_conv_desc *d)
@@ -754,7 +768,11 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
     if (d->upsample && d->stride != 1) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: upsample with stride");
     if (d->out_dtype != GG_BF16 && d->out_dtype != GG_F32) GG_FAIL(GG_ERR_BAD_DTYPE, "conv: out dtype");
     if (!d->src1 || !d->weight || !d->out || (d->C2 && !d->src2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: null pointer");
-    if (d->prologue_act && (!d->gn_scale || !d->gn_shift)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: prologue without scale/shift");
+    const bool pro_acc = d->prologue_act && !d->gn_scale && !d->gn_shift && d->pro_acc1;
+    if (pro_acc) {
+        if (!gg_conv_prologue_from_acc(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot compute its GroupNorm prologue from accumulators (gg_conv_prologue_from_acc)");
+        if (!d->pro_gamma || !d->pro_beta || (d->C2 && !d->pro_acc2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: accumulator prologue needs gamma / beta and one accumulator per source");
+    } else if (d->prologue_act && (!d->gn_scale || !d->gn_shift)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: prologue without scale/shift");
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Do <= 0 || d->Ho <= 0 || d->Wo <= 0) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: empty extent");
     // output extent must match the conv arithmetic (what nn.ConvNd / F.interpolate would produce)
     auto expect = [&](int in, int k, int up) {

@@ -27,6 +27,9 @@
 //     (activation-heavy layers) run on the same XCD and hit its L2 (blockIdx round-robins over the 8 XCDs).
 #include <atomic>
 #include "gg_conv.h"
+#ifndef GG_BOX_ACC_SILU_MAX_ELEMS
+#define GG_BOX_ACC_SILU_MAX_ELEMS 32768      /* in-image elements of a box up to which a SiLU norm is folded into the conv (A/B: tools/experiments) */
+#endif
 #include <stdlib.h>
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14), as builtins so that the
@@ -138,6 +141,33 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // staging duty of a lane inside a 16-row DMA block: row (lane>>2), LDS slot (lane&3)
     const int lrow = lane >> 2, lslot = lane & 3;
 
+    // GroupNorm prologue FROM ACCUMULATORS (gg_conv_desc.pro_acc1): this thread's channels tid + 512k of the per-channel fixed-point
+    // (sum, sumsq) the producing convs left, gamma and beta, requested ahead of the box DMAs (vmcnt counts in order: they have
+    // landed when the box has); folded into the scale / shift table of ALL input channels once the first box is in LDS.
+    const bool acc_mode = p.prologue_act && p.pro_acc1 != nullptr;
+    constexpr int ACPT = 4;                            // channels per thread: C1 + C2 <= 2048 (host gate)
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+    i64x2 pa[ACPT];
+    float pgam[ACPT], pbet[ACPT];
+    __shared__ unsigned long long pro_gacc[32][2];     // per-group integer (sum, sumsq): LDS atomics, exact in any order
+    __shared__ float pro_gmean[32], pro_grstd[32];
+    if (acc_mode) {
+        if (tid < 64) pro_gacc[tid >> 1][tid & 1] = 0ull;
+#pragma unroll
+        for (int k = 0; k < ACPT; ++k) {
+            const int c = tid + 512 * k;
+            pa[k] = i64x2{0, 0};
+            pgam[k] = 0.f;
+            pbet[k] = 0.f;
+            if (c < p.pro_clog) {
+                const long long *q = (c < p.C1) ? p.pro_acc1 + ((long long)n * p.C1 + c) * 2 : p.pro_acc2 + ((long long)n * p.C2 + (c - p.C1)) * 2;
+                pa[k] = *reinterpret_cast<const i64x2 *>(q);
+                pgam[k] = p.pro_gamma[c];
+                pbet[k] = p.pro_beta[c];
+            }
+        }
+    }
+
     for (int st = 0; st < nstage; ++st) {
         const int cbase = st * nch_stage;
         const int nch = (p.nchunk - cbase < nch_stage) ? p.nchunk - cbase : nch_stage;
@@ -146,7 +176,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         const unsigned mnch = nch == nch_stage ? mg.nch : mg.nch_last;       // magic of this stage's chunk count
 
         // GroupNorm scale/shift rows of the stage -> LDS, by DMA as well (256 floats per wave instruction)
-        if (p.prologue_act) {
+        if (p.prologue_act && !acc_mode) {
             const int gn_units = 2 * ((nch + 7) >> 3);
             for (int u = wave; u < gn_units; u += NW) {
                 const int which = u & 1, blk = u >> 1;
@@ -288,7 +318,54 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         }
         GG_BOX_LDS_BARRIER();
 
+        if (acc_mode && st == 0) {
+            // fold: channels -> groups (integer LDS atomics), groups -> mean / rstd (fp64), channels -> scale / shift rows of ALL chunks
+            const int cpg = p.pro_clog >> 5;
+            const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
+#pragma unroll
+            for (int k = 0; k < ACPT; ++k) {
+                const int c = tid + 512 * k;
+                if (c < p.pro_clog) {
+                    const int gg = gg_div_small(c, rcpg);
+                    atomicAdd(&pro_gacc[gg][0], (unsigned long long)pa[k][0]);
+                    atomicAdd(&pro_gacc[gg][1], (unsigned long long)pa[k][1]);
+                }
+            }
+            GG_BOX_LDS_BARRIER();
+            if (tid < 32) {
+                const double a = (double)(long long)pro_gacc[tid][0] * (1.0 / (double)GG_ACC_SUM_SCALE);
+                const double b = (double)(long long)pro_gacc[tid][1] * (1.0 / (double)GG_ACC_SQ_SCALE);
+                const double cnt = (double)p.H * (double)p.W * (double)cpg;
+                double inv = (double)(1.0f / (float)cnt);
+                inv = inv * (2.0 - cnt * inv);                 // fp32 reciprocal + one Newton step in fp64 (as gn_apply_acc_kernel)
+                const double mean = a * inv;
+                double var = b * inv - mean * mean;
+                if (var < 0.0) var = 0.0;
+                pro_gmean[tid] = (float)mean;
+                pro_grstd[tid] = rsqrtf((float)var + p.pro_eps);
+            }
+            GG_BOX_LDS_BARRIER();
+            const int Ct = p.nchunk * 32;
+#pragma unroll
+            for (int k = 0; k < ACPT; ++k) {
+                const int c = tid + 512 * k;
+                if (c < Ct) {
+                    float sc = 0.f, sh = 0.f;
+                    if (c < p.pro_clog) {
+                        const int gg = gg_div_small(c, rcpg);
+                        sc = pro_grstd[gg] * pgam[k];
+                        sh = pbet[k] - pro_gmean[gg] * sc;
+                    }
+                    gns[c] = sc;
+                    gns[Ct + c] = sh;
+                }
+            }
+            GG_BOX_LDS_BARRIER();
+        }
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
+            // rows of the table: external tables hold this stage's chunks only, the accumulator fold holds all chunks of the conv
+            const float *gsc = gns + (acc_mode ? cbase * 32 : 0);
+            const int gsh = (acc_mode ? p.nchunk : nch) * 32;
 #pragma unroll 2
             for (int unit = wave; unit < nunit; unit += NW) {
                 const int c = unit / NRB, rbk = unit - c * NRB;
@@ -298,7 +375,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                 if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
                     const int q = lslot ^ bsw(row, hw);
                     char *pc = box + c * PLANE + rbk * 1024 + lane * 16;
-                    const float *sc = gns + c * 32 + q * 8, *sh = sc + nch * 32;
+                    const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
                     const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sc), sc1 = *reinterpret_cast<const f32x4 *>(sc + 4);
                     const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sh), sh1 = *reinterpret_cast<const f32x4 *>(sh + 4);
                     bf16x8 xb = *reinterpret_cast<const bf16x8 *>(pc), yb;
@@ -537,7 +614,8 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     long long smem = nch_stage * plane;
     const long long red = 8LL * MT * CT * 64 * 16;                   // [wave][tt][ct][lane] f32x4
     if (smem < red) smem = red;
-    const int gn_bytes = p.prologue_act ? (nch_stage * 32 * 8 + 1023) / 1024 * 1024 : 0;
+    // scale / shift rows in front of the box: external tables are DMA'd per stage, the accumulator fold keeps all chunks of the conv
+    const int gn_bytes = p.prologue_act ? ((p.pro_acc1 ? p.nchunk : nch_stage) * 32 * 8 + 1023) / 1024 * 1024 : 0;
     // XCD locality: a run of workgroups shares weights (cout-major) when the weights are the bigger re-fetch, else boxes
     const long long P = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI), Q = p.Cout_pad / (16 * CT);
     const long long wtot = wbytes16 * (p.Cout_pad / 16), xtot = (long long)p.N * p.H * p.W * p.nchunk * 64;
@@ -600,6 +678,20 @@ bool gg_conv_box_fuses_prologue(const ConvParams &p)
 }
 
 bool gg_conv_box_emits_stats(const ConvParams &p) { return p.out_dtype != GG_F32; }
+
+// Prologue computed from accumulators inside the conv (gg_conv_desc.pro_acc1).  The fold itself is ~0.5 us per workgroup; what decides
+// is the in-place transform, redone by every cout tile that shares a box: an affine-only norm (attention / SpatialTransformer: no
+// SiLU) is a handful of VALU per 16-byte piece and always pays against the ~4.5 us GroupNorm launch it removes; a SiLU norm is
+// transcendental-bound (2 per element) and pays only where few cout tiles share a box (as with external tables) or the in-image part of
+// the box is small (the 4x4 level: <= 64 elements per thread).
+bool gg_conv_box_prologue_from_acc(const ConvParams &p)
+{
+    BoxPlan pl;
+    if (!plan_box(p, pl) || p.C1 + p.C2 > 2048 || !p.prologue_act) return false;
+    if (p.prologue_act == 2) return true;
+    constexpr long long silu_max_elems = GG_BOX_ACC_SILU_MAX_ELEMS;
+    return p.Cout_pad / (16 * pl.CT) <= 2 || (long long)p.H * p.W * (p.C1 + p.C2) <= silu_max_elems;
+}
 
 // Returns GG_ERR_UNSUPPORTED (silently) when the shape is outside the envelope.  stream == (hipStream_t)-1: dry run.
 int gg_conv_box_try(const ConvParams &p, hipStream_t stream)

@@ -200,6 +200,28 @@ def conv_out_extent(in_sp: Sequence[int], k: Sequence[int], stride: int, pad: in
     return tuple(out)
 
 
+def conv_prologue_from_acc(src1: CL, cout: int, act: bool, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
+                           src2: Optional[CL] = None, **_ignored) -> bool:
+    """True if this conv can compute act(GroupNorm(cat[src1, src2])) itself from the accumulators its producers left (CL.acc, 1-stripe
+    layout): no statistics, scale / shift or apply launch at all (gg_conv_desc.pro_acc1)."""
+    if not PROLOGUE_FROM_ACC or is_f32(src1.t) or not has_stats(src1, src2):
+        return False
+    lib = _lib.load()
+    N, D, H, W, C1 = src1.t.shape
+    Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
+    d = ConvDesc()
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = C1, (src2.t.shape[-1] if src2 is not None else 0)
+    d.Cout, d.Cout_pad = cout, pad32(cout)
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.prologue_act = 1 if act else 2
+    d.pro_c_logical = src1.C + (src2.C if src2 is not None else 0)
+    d.path_hint = PATH_HINT
+    return bool(lib.gg_conv_prologue_from_acc(C.byref(d)))
+
+
 def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
                         src2: Optional[CL] = None, **_ignored) -> bool:
     """True if this conv runs on the halo-tile kernel (GroupNorm prologue applied once per element while staging)."""
@@ -222,6 +244,8 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 # ---- GroupNorm statistics emitted by conv epilogues (gg_conv_desc.gn_acc).  One int64 arena per device, bump-allocated per
 # network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
 GN_ACC = True
+TINY_IMAGE_POSITIONS = 16           # outputs with at most this many positions per sample (the 4x4 level) always leave their sums: the next SiLU norm is folded into its conv
+PROLOGUE_FROM_ACC = True            # box convs fold their producers' accumulators themselves where gg_conv_prologue_from_acc says so (A/B switch)
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
 GN_ACC_MIN_ELEMS = 1 << 17          # below this the one-launch GroupNorm kernels are as fast (probe_gn_acc_min.py: 2^18 1593, 2^17 1586, 2^16 1590, 2^15 1604 us per forward)
 _ARENA_ENTRIES = 1 << 19            # 4 MiB of int64 (the latent UNet at batch 1 uses ~0.4 M entries)
@@ -261,8 +285,11 @@ def _stats_alloc(device, N: int, cp: int, stripes: int) -> Optional[torch.Tensor
 def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1,
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
-         out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None, geglu: bool = False) -> CL:
-    """ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
+         out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None, geglu: bool = False, prologue_acc: Optional[tuple] = None,
+         want_stats: bool = False) -> CL:
+    """prologue_acc = (gamma, beta, eps): GroupNorm prologue computed inside the conv from src1.acc / src2.acc (conv_prologue_from_acc);
+    want_stats: leave the output's GroupNorm sums behind whatever its size (the consumer will fold them itself);
+    ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
     runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step."""
     lib = _lib.load()
     t1 = src1.t
@@ -302,7 +329,12 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
     d.Do, d.Ho, d.Wo = Do, Ho, Wo
     d.out_dtype = GG_F32 if out.dtype == torch.float32 else GG_BF16
-    d.prologue_act = (1 if prologue_silu else 2) if prologue is not None else 0
+    d.prologue_act = (1 if prologue_silu else 2) if (prologue is not None or prologue_acc is not None) else 0
+    if prologue_acc is not None:
+        d.pro_gamma, d.pro_beta, d.pro_eps = prologue_acc[0].data_ptr(), prologue_acc[1].data_ptr(), float(prologue_acc[2])
+        d.pro_acc1 = src1.acc.data_ptr()
+        d.pro_acc2 = src2.acc.data_ptr() if src2 is not None else None
+        d.pro_c_logical = src1.C + (src2.C if src2 is not None else 0)
     d.path_hint = PATH_HINT
     d.src1 = t1.data_ptr()
     d.src2 = _ptr(src2.t) if src2 is not None else None
@@ -323,7 +355,8 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         # box / 160-step kernels (1 stripe): only where the norm is launch-bound; halo-tile kernel (32 stripes): always -- there the
         # sums replace a statistics PASS over a 17..805 MB tensor
         stripes = lib.gg_conv_emits_stats(C.byref(d))
-        if stripes == 32 or (stripes and GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS):
+        want = want_stats or (PROLOGUE_FROM_ACC and Do * Ho * Wo <= TINY_IMAGE_POSITIONS)
+        if stripes == 32 or (stripes and (want or GN_ACC_MIN_ELEMS <= Do * Ho * Wo * cp) and Do * Ho * Wo * cp <= GN_ACC_MAX_ELEMS):
             acc = _stats_alloc(t1.device, N, cp, stripes)
             if acc is not None:
                 d.gn_acc = acc.data_ptr()

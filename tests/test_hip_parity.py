@@ -1052,3 +1052,44 @@ def test_fp32_validation_kernels_vs_torch(dev):
         assert e < 1e-5
     # leaving the mode: the production (bf16) packs are used again
     assert ops.to_cl(x.to(dev)).t.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("cfg", [(1, 640, 1920, (16, 16), 1, False), (1, 640, 1920, (8, 8), 1, False), (2, 320, 960, (8, 16), 1, False),
+                                 (1, 800, 800, (4, 4), 3, True), (1, 160, 4, (64, 64), 3, True), (1, 1280, 640, (8, 8), 1, False)],
+                         ids=["qkv_16x16", "qkv_8x8", "qkv_n2", "silu_4x4_3x3", "head_64x64", "two_stage_1x1"])
+def test_conv_groupnorm_prologue_from_accumulators(dev, cfg, monkeypatch):
+    """gg_conv_desc.pro_acc1: a box-kernel conv folds the (sum, sumsq) accumulators its producer left into the GroupNorm scale / shift
+    table itself and normalises (* SiLU) its staged box in place -- no GroupNorm launch.  Producer = a real box conv emitting the sums;
+    compared with the oracle's conv(act(GroupNorm(y))) on the stored bf16 tensor, with the launch-based path, and twice for
+    bit-reproducibility; two-source concat for the cases that allow it."""
+    from jointimagegeneration_amd import ops
+    N, C, Cout, sp, k, act = cfg
+    g = torch.Generator().manual_seed(C + Cout + k)
+    x = torch.randn((N, C) + sp, generator=g)
+    w0 = torch.randn(C, C, 1, 1, generator=g) / math.sqrt(C)
+    w = torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xcl = ops.to_cl(x.to(dev))
+    ops.stats_begin(dev)
+    try:
+        y = ops.conv(xcl, ops.pack_conv_weight(w0.to(dev), xcl.Cpad), None, C, k=(1, 1, 1), pad=0, want_stats=True)      # producer (box 1x1 / gather5)
+        if y.acc is None or y.acc.shape[1] != 1:
+            pytest.skip("producer shape does not emit 1-stripe sums")
+        kw = dict(k=(1, k, k), pad=k // 2)
+        assert ops.conv_prologue_from_acc(y, Cout, act, **kw)
+        pw, pb = ops.pack_conv_weight(w.to(dev), y.Cpad), ops.pad_bias(b.to(dev), Cout, dev)
+        outs = [ops.conv(y, pw, pb, Cout, prologue_acc=(gamma.to(dev), beta.to(dev), 1e-5), prologue_silu=act, **kw) for _ in range(2)]
+        assert torch.equal(outs[0].t, outs[1].t)
+        yf = ops.from_cl(y, 2).cpu()
+        a = O.group_norm(yf, gamma, beta, 1e-5)
+        a = O.silu(a) if act else a
+        ref = O.conv(bf(a), bf(w), b, padding=k // 2)
+        got = ops.from_cl(outs[0], 2).cpu()
+        assert rel_err(got, ref) < 1.5e-2, rel_err(got, ref)
+        # launch-based path on the same tensor: statistics pass + apply + conv
+        sc, sh = ops.groupnorm_stats(y, gamma.to(dev), beta.to(dev), 1e-5)
+        old = ops.conv(ops.groupnorm_apply(y, sc, sh, act), pw, pb, Cout, **kw)
+        assert rel_err(got, ops.from_cl(old, 2).cpu()) < 1e-2
+    finally:
+        ops.stats_end(dev)
