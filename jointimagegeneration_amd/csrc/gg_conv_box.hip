@@ -146,22 +146,16 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // landed when the box has); folded into the scale / shift table of ALL input channels once the first box is in LDS.
     const bool acc_mode = p.prologue_act && p.pro_acc1 != nullptr;
     constexpr int ACPT = 4;                            // channels per thread: C1 + C2 <= 2048 (host gate)
-    typedef __attribute__((ext_vector_type(2))) long long i64x2;
-    i64x2 pa[ACPT];
     float pgam[ACPT], pbet[ACPT];
-    __shared__ unsigned long long pro_gacc[32][2];     // per-group integer (sum, sumsq): LDS atomics, exact in any order
+    long long psum = 0;                                // 8 lanes per (group, sum | sumsq) task
     __shared__ float pro_gmean[32], pro_grstd[32];
     if (acc_mode) {
-        if (tid < 64) pro_gacc[tid >> 1][tid & 1] = 0ull;
 #pragma unroll
         for (int k = 0; k < ACPT; ++k) {
             const int c = tid + 512 * k;
-            pa[k] = i64x2{0, 0};
             pgam[k] = 0.f;
             pbet[k] = 0.f;
             if (c < p.pro_clog) {
-                const long long *q = (c < p.C1) ? p.pro_acc1 + ((long long)n * p.C1 + c) * 2 : p.pro_acc2 + ((long long)n * p.C2 + (c - p.C1)) * 2;
-                pa[k] = *reinterpret_cast<const i64x2 *>(q);
                 pgam[k] = p.pro_gamma[c];
                 pbet[k] = p.pro_beta[c];
             }
@@ -305,6 +299,25 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         for (int r = 0; r < NTRIP; ++r) load_w(wr[r]);
         // the box (and the scale/shift rows) have landed once at most this wave's NTRIP*4*CT weight loads are outstanding
         GG_STAMP(2);
+        if (acc_mode && st == 0) {
+            // 64 tasks (32 groups x {sum, sumsq}), 8 lanes each: lane `part` reads channels part, part + 8, ... of the group's cpg <= 64
+            // per-channel fixed-point sums straight from L2 -- at most 8 loads per lane, ALL in flight at once, while the box is landing
+            // (no LDS atomics, no staging area; integer adds are exact in any order)
+            const int task = tid >> 3, part = tid & 7, gg = task >> 1, which = task & 1;
+            const int cpg = p.pro_clog >> 5;
+            long long v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = part + 8 * i, c = gg * cpg + j;
+                v[i] = 0;
+                if (j < cpg) {
+                    const long long *q = (c < p.C1) ? p.pro_acc1 + ((long long)n * p.C1 + c) * 2 : p.pro_acc2 + ((long long)n * p.C2 + (c - p.C1)) * 2;
+                    v[i] = q[which];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) psum += v[i];
+        }
         // this wave's DMAs have landed once only its NTRIP*SPT*CT weight loads are outstanding; then zero ITS padding slots; then barrier
         __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * SPT * CT));
         if (ih0 < 0 || iw0 < 0 || ih0 + HH > p.H || iw0 + HW > p.W) {        // border workgroups only (wave-uniform)
@@ -319,30 +332,26 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         GG_BOX_LDS_BARRIER();
 
         if (acc_mode && st == 0) {
-            // fold: channels -> groups (integer LDS atomics), groups -> mean / rstd (fp64), channels -> scale / shift rows of ALL chunks
+            // groups -> mean / rstd (fp64; the sum | sumsq lanes of a group are neighbours), channels -> scale / shift rows of ALL chunks
             const int cpg = p.pro_clog >> 5;
             const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
-#pragma unroll
-            for (int k = 0; k < ACPT; ++k) {
-                const int c = tid + 512 * k;
-                if (c < p.pro_clog) {
-                    const int gg = gg_div_small(c, rcpg);
-                    atomicAdd(&pro_gacc[gg][0], (unsigned long long)pa[k][0]);
-                    atomicAdd(&pro_gacc[gg][1], (unsigned long long)pa[k][1]);
+            {
+                psum += __shfl_xor(psum, 1);
+                psum += __shfl_xor(psum, 2);
+                psum += __shfl_xor(psum, 4);                   // the 8 parts of a task
+                const long long other = __shfl_xor(psum, 8);   // sumsq task of the same group sits 8 lanes up
+                if ((tid & 15) == 0) {
+                    const double a = (double)psum * (1.0 / (double)GG_ACC_SUM_SCALE);
+                    const double b = (double)other * (1.0 / (double)GG_ACC_SQ_SCALE);
+                    const double cnt = (double)p.H * (double)p.W * (double)cpg;
+                    double inv = (double)(1.0f / (float)cnt);
+                    inv = inv * (2.0 - cnt * inv);             // fp32 reciprocal + one Newton step in fp64 (as gn_apply_acc_kernel)
+                    const double mean = a * inv;
+                    double var = b * inv - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    pro_gmean[tid >> 4] = (float)mean;
+                    pro_grstd[tid >> 4] = rsqrtf((float)var + p.pro_eps);
                 }
-            }
-            GG_BOX_LDS_BARRIER();
-            if (tid < 32) {
-                const double a = (double)(long long)pro_gacc[tid][0] * (1.0 / (double)GG_ACC_SUM_SCALE);
-                const double b = (double)(long long)pro_gacc[tid][1] * (1.0 / (double)GG_ACC_SQ_SCALE);
-                const double cnt = (double)p.H * (double)p.W * (double)cpg;
-                double inv = (double)(1.0f / (float)cnt);
-                inv = inv * (2.0 - cnt * inv);                 // fp32 reciprocal + one Newton step in fp64 (as gn_apply_acc_kernel)
-                const double mean = a * inv;
-                double var = b * inv - mean * mean;
-                if (var < 0.0) var = 0.0;
-                pro_gmean[tid] = (float)mean;
-                pro_grstd[tid] = rsqrtf((float)var + p.pro_eps);
             }
             GG_BOX_LDS_BARRIER();
             const int Ct = p.nchunk * 32;
@@ -366,30 +375,49 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             // rows of the table: external tables hold this stage's chunks only, the accumulator fold holds all chunks of the conv
             const float *gsc = gns + (acc_mode ? cbase * 32 : 0);
             const int gsh = (acc_mode ? p.nchunk : nch) * 32;
-#pragma unroll 2
-            for (int unit = wave; unit < nunit; unit += NW) {
-                const int c = unit / NRB, rbk = unit - c * NRB;
-                const int row = rbk * 16 + lrow;
-                const int hh = row / HW, hw = row - hh * HW;
-                const int ih = ih0 + hh, iw = iw0 + hw;
-                if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                    const int q = lslot ^ bsw(row, hw);
-                    char *pc = box + c * PLANE + rbk * 1024 + lane * 16;
+            auto xform = [&](char *pc, const f32x4 sc0, const f32x4 sc1, const f32x4 sh0, const f32x4 sh1) {
+                bf16x8 xb = *reinterpret_cast<const bf16x8 *>(pc), yb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y0 = (float)xb[e] * sc0[e] + sh0[e], y1 = (float)xb[e + 4] * sc1[e] + sh1[e];
+                    if (p.prologue_act == 1) {
+                        y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                        y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                    }
+                    yb[e] = (bf16_t)y0;
+                    yb[e + 4] = (bf16_t)y1;
+                }
+                *reinterpret_cast<bf16x8 *>(pc) = yb;
+            };
+            if constexpr (!K3) {
+                // 1x1 boxes (row-based swizzle): the lane's 8 channels of a chunk are the same in every 16-row block, so its scale / shift
+                // rows are read once per chunk, not once per piece
+                const int q = lslot ^ bsw(lrow, 0);
+                for (int c = wave; c < nch; c += NW) {
                     const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
                     const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sc), sc1 = *reinterpret_cast<const f32x4 *>(sc + 4);
                     const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sh), sh1 = *reinterpret_cast<const f32x4 *>(sh + 4);
-                    bf16x8 xb = *reinterpret_cast<const bf16x8 *>(pc), yb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float y0 = (float)xb[e] * sc0[e] + sh0[e], y1 = (float)xb[e + 4] * sc1[e] + sh1[e];
-                        if (p.prologue_act == 1) {
-                            y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
-                            y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
-                        }
-                        yb[e] = (bf16_t)y0;
-                        yb[e + 4] = (bf16_t)y1;
+#pragma unroll 2
+                    for (int rbk = 0; rbk < NRB; ++rbk) {
+                        const int row = rbk * 16 + lrow;
+                        const int hh = row / HW, hw = row - hh * HW;
+                        const int ih = ih0 + hh, iw = iw0 + hw;
+                        if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xform(box + c * PLANE + rbk * 1024 + lane * 16, sc0, sc1, sh0, sh1);
                     }
-                    *reinterpret_cast<bf16x8 *>(pc) = yb;
+                }
+            } else {
+#pragma unroll 2
+                for (int unit = wave; unit < nunit; unit += NW) {
+                    const int c = unit / NRB, rbk = unit - c * NRB;
+                    const int row = rbk * 16 + lrow;
+                    const int hh = row / HW, hw = row - hh * HW;
+                    const int ih = ih0 + hh, iw = iw0 + hw;
+                    if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
+                        const int q = lslot ^ bsw(row, hw);
+                        const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
+                        xform(box + c * PLANE + rbk * 1024 + lane * 16, *reinterpret_cast<const f32x4 *>(sc), *reinterpret_cast<const f32x4 *>(sc + 4),
+                              *reinterpret_cast<const f32x4 *>(sh), *reinterpret_cast<const f32x4 *>(sh + 4));
+                    }
                 }
             }
             GG_BOX_LDS_BARRIER();
