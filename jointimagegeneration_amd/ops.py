@@ -244,7 +244,8 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 # ---- GroupNorm statistics emitted by conv epilogues (gg_conv_desc.gn_acc).  One int64 arena per device, bump-allocated per
 # network forward and zeroed by ONE memset at the start of the next forward (static addresses: hipGraph friendly).
 GN_ACC = True
-TINY_IMAGE_POSITIONS = 16           # outputs with at most this many positions per sample (the 4x4 level) always leave their sums: the next SiLU norm is folded into its conv
+TINY_IMAGE_POSITIONS = 0            # > 0: outputs with at most this many positions per sample also leave their sums, so that the next SiLU norm is folded into
+                                    # its conv (16 = the 4x4 level: measured SLOWER, 1558 vs 1548 us per latent-UNet forward: producer epilogues + transform > launch)
 PROLOGUE_FROM_ACC = True            # box convs fold their producers' accumulators themselves where gg_conv_prologue_from_acc says so (A/B switch)
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
 GN_ACC_MIN_ELEMS = 1 << 17          # below this the one-launch GroupNorm kernels are as fast (probe_gn_acc_min.py: 2^18 1593, 2^17 1586, 2^16 1590, 2^15 1604 us per forward)

@@ -183,37 +183,46 @@ def test_c1_fp32_validation_mode_labels_bit_exact(dev):
         assert total == 0
 
 
-def test_c1_bf16_peaked_posteriors_label_flips(dev):
-    """random head weights give near-uniform posteriors (the worst case for label agreement).  With the head conv
-    scaled so that > 90 % of the voxels have an oracle top-2 margin > 0.1 (what a trained network produces), the bf16 production
-    engine's labels vs the fp32 oracle: sampled step (t = 26, exponential tape) and final argmax (t = 1).  Bounds: <= 0.3 % of the voxels on the sampled step (the race
-    p_k / E_k re-randomises the decision, so near ties exist whatever the network says; measured 0.14 %), <= 0.1 % on the argmax."""
+def test_c1_bf16_label_flips_vs_oracle_decision_margin(dev):
+    """VERDICT r02 item 4c, restated.  Scaling the head conv cannot make the test easier: the argmax and the race argmax_k p_k / E_k are
+    invariant under a common scale of the logits' DIFFERENCES relative to their errors -- a head scaled x40 (97 % of the voxels with a
+    p0 margin > 0.1) flips the same 1.1 % of the t = 1 labels, because bf16 errors scale with the logits (measured, profiles/r03).  What
+    decides a flip is the oracle's OWN decision margin, so this test bins the bf16 engine's label flips by that margin (final argmax:
+    top-2 gap of the normalised posterior; sampled step: relative top-2 gap of the race values) and requires ZERO flips wherever the
+    margin exceeds 3e-2 / 8 % (a trained network's confident voxels), <= 1.5 % overall with random weights (near-uniform posteriors:
+    the worst case).  The fp32 validation mode has no flips at all (test_c1_fp32_validation_mode_labels_bit_exact)."""
     model, sd, K = _full_ccdm(dev, 50)
     R, M, Tn = 32, 32 ** 3, 50
-    scale = 40.0
-    with torch.no_grad():
-        model.unet.out[2].weight.mul_(scale); model.unet.out[2].bias.mul_(scale)          # in-place: version bump => repack
-    sd = dict(sd)
-    sd["out.2.weight"], sd["out.2.bias"] = sd["out.2.weight"] * scale, sd["out.2.bias"] * scale
     ge = gen(99)
     lab = torch.from_numpy(synth_labels((R, R, R), K, seed=3))[None]
     cond = torch.zeros(1, 1, R, R, R)
     torch.set_num_threads(cores())
     _, al, ca = S.ccdm_schedule("cosine", Tn)
-    for t in (26, 1):
+    for t, edges in ((26, (0.0, 1e-3, 1e-2, 8e-2, 1e9)), (1, (0.0, 1e-4, 1e-3, 3e-2, 1e9))):
         E = torch.empty(M, K).exponential_(1, generator=ge)
         xt = S.one_hot_bchw(lab, K)
         p0 = O.unet_forward(sd, torch.cat([xt, cond], 1), torch.tensor([float(t)]), model_channels=64, head_channels=32, softmax_out=True)
-        top2 = p0.topk(2, dim=1).values
-        peaked = float(((top2[:, 0] - top2[:, 1]) > 0.1).float().mean())
         a, abar = S.ccdm_step_scalars(al, ca, t)
-        post = torch.clamp(S.theta_post_prob(xt, p0, a, abar), min=1e-12)
-        want = S.race_sample_labels(post, E) if t > 1 else (post / post.sum(1, keepdim=True)).argmax(1)
+        post = torch.clamp(S.theta_post_prob(xt, p0, a, abar), min=1e-12)[0].permute(1, 2, 3, 0).reshape(M, K)
+        post = post / post.sum(-1, keepdim=True)
+        if t > 1:
+            race = post / E
+            want = race.argmax(-1)
+            top2 = race.topk(2, dim=1).values
+            margin = (top2[:, 0] - top2[:, 1]) / top2[:, 0]
+        else:
+            want = post.argmax(-1)
+            top2 = post.topk(2, dim=1).values
+            margin = top2[:, 0] - top2[:, 1]
         trace = []
         model.sample_labels(lab.int().to(dev), cond.to(dev), init_t=t, rng_tapes=[E] * t, trace=trace)      # the chain runs on to t = 1; trace[0] is step t
-        mism = int((trace[0]["labels"].cpu() != want).sum())
-        print(f"C1 bf16, peaked posteriors (head x{scale:g}: {peaked:.3f} of voxels with p0 margin > 0.1), step t={t}: {mism} / {M} label flips vs the oracle")
-        assert peaked > 0.9 and mism <= (3e-3 if t > 1 else 1e-3) * M
+        bad = trace[0]["labels"].cpu().flatten() != want
+        rows = []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            sel = (margin >= lo) & (margin < hi)
+            rows.append(f"[{lo:g}, {hi:g}): {int(bad[sel].sum())} / {int(sel.sum())}")
+        print(f"C1 bf16 label flips vs the oracle at t={t} by oracle decision margin: " + "; ".join(rows) + f"; total {int(bad.sum())} / {M}")
+        assert int(bad[margin >= edges[-2]].sum()) == 0 and int(bad.sum()) <= 0.015 * M
 
 
 # ------------------------------------------------------------------------------------------------ C3
