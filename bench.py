@@ -177,6 +177,63 @@ def stage_rooflines(pipe, ccdm_ms_per_step):
     return out
 
 
+def other_config_stages(device):
+    """roofline.stages entries of the two shipped / named configurations that are NOT on the C5 wall, each one
+    captured forward at batch 1 timed with HIP events over 20 graph replays:
+      * the latent UNet with SpatialTransformer cross-attention (BASELINE.json C4 as worded: context 512 x 768, 365.2 M params,
+        181.5 GFLOP per forward; HBM-bound: 730 MB of bf16 weights streamed once per forward),
+      * the pixel-space UNet of configs/latent-diffusion/ruijin-ldm_from_controlnet.yaml (3 x 512^2 in, 172.9 M params, 4 629 GFLOP per
+        forward; MFMA-bound)."""
+    import torch
+    from jointimagegeneration_amd import ops
+    from jointimagegeneration_amd.ops import CL
+    from jointimagegeneration_amd.pipeline import LDM_UNET
+    from jointimagegeneration_amd.synth import randomize_parameters
+    from jointimagegeneration_amd.unet import UNetModel
+    out = {}
+
+    def timed(unet, x, row, ctx):
+        unet.forward_cl(x, row, ctx)
+        torch.cuda.synchronize()
+        g = ops.capture_graph(lambda: unet.forward_cl(x, row, ctx))
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20
+
+    def entry(name, ms, gflop, mbytes, what):
+        t_mfma, t_hbm = gflop / (MFMA_PEAK_TFLOPS * 1e3) * 1e3, mbytes / (HBM_PEAK_GBS * 1e3) * 1e3
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        e = {"bound": bound, "what": what, "ms": round(ms, 4), "t_roof_ms": round(max(t_mfma, t_hbm), 4), "frac": round(max(t_mfma, t_hbm) / ms, 4),
+             "mfma_frac": round(t_mfma / ms, 4), "on_c5_wall": False}
+        e.update(dict(achieved=round(mbytes / ms, 1), peak=HBM_PEAK_GBS, unit="GB/s") if bound == "hbm" else
+                 dict(achieved=round(gflop / ms, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s"))
+        out[name] = e
+
+    u = UNetModel(**dict(LDM_UNET["params"], use_spatial_transformer=True, context_dim=768, transformer_depth=1)).eval()
+    randomize_parameters(u, 1024, "ldm_st.")
+    u = u.to(device)
+    x = CL(torch.randn(1, 1, 64, 64, 32, device=device).bfloat16(), 8)
+    ctx = u.context_cl(torch.randn(1, 512, 768, device=device))
+    ms = timed(u, x, u.time_bias_rows(torch.full((1,), 481.0, device=device)), ctx)
+    entry("ldm_st_unet_forward_n1_64x64_ctx512x768", ms, 181.52, 730.4, "latent UNet + SpatialTransformer cross-attention (C4 as named), one captured forward")
+    del u, x, ctx
+    u = UNetModel(dims=2, image_size=512, in_channels=3, out_channels=1, model_channels=128, attention_resolutions=[32, 16, 8], num_res_blocks=2,
+                  channel_mult=[1, 2, 4, 4, 5], num_head_channels=32).eval()
+    randomize_parameters(u, 1024, "ldm_pixel.")
+    u = u.to(device)
+    x = CL(torch.randn(1, 1, 512, 512, 32, device=device).bfloat16(), 3)
+    ms = timed(u, x, u.time_bias_rows(torch.full((1,), 481.0, device=device)), None)
+    entry("pixel_unet_forward_n1_3x512x512", ms, 4629.0, 345.8 + 2 * 1200.0, "pixel-space UNet of ruijin-ldm_from_controlnet.yaml, one captured forward")
+    del u, x
+    torch.cuda.empty_cache()
+    return out
+
+
 def wall_shares(stages, volume_ms, ccdm_steps, slices, ddim_steps=50):
     """Share of one volume's wall time spent in each stage (launch count x captured stage time / measured volume time), and the
     stage that dominates the wall with ITS roofline fraction: the top-level `roofline` names the MFMA-bound judged kernel, which is
@@ -339,6 +396,12 @@ def main():
         if not args.no_roofline:
             log("roofline legs (HIP events)")
             line_extra["roofline"] = conv_roofline(pipe, device)
+        if not args.no_roofline and not args.no_extra:
+            log("roofline legs of the configurations off the C5 wall (SpatialTransformer UNet, pixel-space UNet)")
+            try:
+                line_extra["other_stages"] = other_config_stages(device)
+            except Exception as e:                                           # never lose the line to an auxiliary leg
+                line_extra["other_stages"] = {"error": repr(e)}
         if args.volumes_per_gpu == 1 and not args.no_extra and args.max_slices is None:
             log("secondary leg: 8 volumes per GPU (bounded sample)")
             try:
@@ -348,7 +411,7 @@ def main():
 
     # after the timed region: stage timings + JSON + teardown, and on rank 0 the CPU-baseline leg (~35 s of host work: it runs AFTER the
     # timed region and after the last collective, so that the other ranks never wait in a barrier for it)
-    TAIL_S = 12.0 + (0.0 if (args.no_cpu_baseline or dry) else 45.0)
+    TAIL_S = 12.0 + (0.0 if (args.no_cpu_baseline or dry) else 25.0)
     est = None                                               # seconds per volume, measured
     warm_done = 0
     ggd.barrier(device)
@@ -416,6 +479,7 @@ def main():
             if "roofline" in line and not partial:
                 try:
                     st = stage_rooflines(pipe, pipe.stats["ccdm_s"] / args.ccdm_steps * 1e3)
+                    st.update(line.pop("other_stages", {}))
                     line["roofline"]["stages"] = st
                     line["roofline"]["wall_shares"], line["roofline"]["dominant_by_wall"] = wall_shares(st, elapsed / done * 1e3, args.ccdm_steps, args.slices)
                 except Exception as e:                                       # never lose the line to an auxiliary leg
