@@ -194,8 +194,14 @@ typedef struct {
     int32_t reserved;
     const void *q, *k, *v;          /* bf16 */
     void *out;                      /* bf16 */
+    void *workspace;                /* optional caller-owned scratch of gg_attention_workspace_bytes(desc) bytes: under-filled single-head
+                                       grids (AE mid-block attention, one head of 384 / 512 channels over 4096 tokens) then split the KEYS over
+                                       several workgroups and merge the online-softmax states in a second launch; NULL / too small: unsplit */
+    int64_t workspace_bytes;
 } gg_attention_desc;
 int gg_attention_forward(const gg_attention_desc *desc, void *stream);
+/* Scratch bytes with which gg_attention_forward splits the keys of this shape (0: it never splits it); pointers are not read. */
+int64_t gg_attention_workspace_bytes(const gg_attention_desc *desc);
 
 /* LayerNorm over the last dim (nn.LayerNorm eps 1e-5, attention.py:203-205), bf16 rows -> bf16 rows. */
 int gg_layernorm(const void *x, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,

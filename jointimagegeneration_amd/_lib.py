@@ -35,7 +35,7 @@ class AttentionDesc(C.Structure):
         ("N", i32), ("heads", i32), ("head_dim", i32), ("Tq", i32), ("Tkv", i32),
         ("ldq", i64), ("hsq", i64), ("ldk", i64), ("hsk", i64), ("ldv", i64), ("hsv", i64), ("ldo", i64), ("hso", i64),
         ("scale", f32), ("reserved", i32),
-        ("q", vp), ("k", vp), ("v", vp), ("out", vp),
+        ("q", vp), ("k", vp), ("v", vp), ("out", vp), ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "gg_groupnorm_fused": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, i32, vp, vp]),
     "gg_groupnorm_scale_shift_acc": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp]),
     "gg_attention_forward": (C.c_int, [C.POINTER(AttentionDesc), vp]),
+    "gg_attention_workspace_bytes": (i64, [C.POINTER(AttentionDesc)]),
     "gg_layernorm": (C.c_int, [vp, i64, i32, vp, vp, f32, vp, vp]),
     "gg_geglu": (C.c_int, [vp, i64, i32, vp, vp]),
     "gg_add": (C.c_int, [vp, vp, i64, vp, vp]),

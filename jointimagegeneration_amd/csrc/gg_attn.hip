@@ -15,6 +15,10 @@ struct AttnParams {
     float scale_log2;
     const bf16_t *q, *k, *v;
     bf16_t *out;
+    // key split (flash-decoding): block s of `ksplit` handles keys [s * kchunk, (s + 1) * kchunk) and leaves its UNNORMALISED state
+    // (o fp32 [.., D], m, l) in the workspace; attn_merge_kernel combines the states.  ksplit == 1: plain kernel.
+    int ksplit, kchunk;
+    float *ws_o, *ws_ml;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -47,7 +51,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (LDS-DMA destinations live in M0)
     const int fr = lane & 15, g = lane >> 4;
     const int n = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int qt = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x, ksp = p.ksplit > 1 ? blockIdx.x - qt * p.ksplit : 0;
+    const int q0 = qt * 64 + wave * 16;
+    const int kbeg = ksp * p.kchunk, kend = (p.ksplit > 1 && kbeg + p.kchunk < p.Tkv) ? kbeg + p.kchunk : p.Tkv;     // kchunk % KT == 0
 
     // Q fragments (B operand: col = query fr, k = 8g + j)
     bf16x8 qf[KS];
@@ -102,12 +108,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
             }
         }
     };
-    if (DMA) stage_dma(0, 0);
-    if (!DMA && PREFETCH) fetch(0);
+    if (DMA) stage_dma(kbeg, 0);
+    if (!DMA && PREFETCH) fetch(kbeg);
     int tile = 0;
-    for (int key0 = 0; key0 < p.Tkv; key0 += KT, ++tile) {
+    for (int key0 = kbeg; key0 < kend; key0 += KT, ++tile) {
         if (DMA) {
-            const bool more = key0 + KT < p.Tkv;
+            const bool more = key0 + KT < kend;
             if (more) stage_dma(key0 + KT, (tile + 1) & 1);          // the other buffer: last read one tile ago, barrier since
             // this wave's 2*KT/4 DMAs of the current tile have landed once at most the next tile's are outstanding
             if (more) __builtin_amdgcn_s_waitcnt(((2 * KT / 4) & 15) | (((2 * KT / 4) >> 4) << 14) | 0x0F70);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
             }
         }
         __syncthreads();
-        if (PREFETCH && key0 + KT < p.Tkv) fetch(key0 + KT);
+        if (PREFETCH && key0 + KT < kend) fetch(key0 + KT);
         }
 
         // One online-softmax step covers G x 32 keys (up to 128): the max / sum lane reductions and the rescale of O happen once
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
         constexpr int G = KT / 32 >= 4 ? 4 : KT / 32;
 #pragma unroll
         for (int sub0 = 0; sub0 < KT / 32; sub0 += G) {
-            if (key0 + sub0 * 32 >= p.Tkv) break;
+            if (key0 + sub0 * 32 >= kend) break;
             // ---- S^T for G x 32 keys: 2G 16-key tiles
             f32x4 s[G][2];
 #pragma unroll
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
             //      applied inside the exponent's FMA (scale > 0 commutes with the max), the key mask exists only on a ragged LAST tile
             //      (wave-uniform branch), and v_exp_f32 is used bare (arguments <= 0; results below 2^-126 may flush to zero, they are
             //      rounded to bf16 anyway).
-            const bool ragged = key0 + (sub0 + G) * 32 > p.Tkv;
+            const bool ragged = key0 + (sub0 + G) * 32 > kend;
             if (ragged) {
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi)
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = key0 + (sub0 + gi) * 32 + kt * 16 + 4 * g + r;
-                            s[gi][kt][r] = (key < p.Tkv) ? s[gi][kt][r] : -INFINITY;
+                            s[gi][kt][r] = (key < kend) ? s[gi][kt][r] : -INFINITY;
                         }
             }
             float mx = -INFINITY;
@@ -229,6 +235,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     }
 
     const int qi = q0 + fr;
+    if (p.ksplit > 1) {
+        if (qi < p.Tq) {          // unnormalised partial state of this key range
+            const long long row = (((long long)n * p.heads + h) * p.ksplit + ksp) * p.Tq + qi;
+            float *op = p.ws_o + row * D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(op + dt * 16) = o[dt];
+            if (g == 0) { p.ws_ml[row * 2] = m_run; p.ws_ml[row * 2 + 1] = l_run; }
+        }
+        return;
+    }
     if (qi < p.Tq) {
         const float inv = 1.0f / l_run;
         bf16_t *op = p.out + ((long long)n * p.Tq + qi) * p.ldo + (long long)h * p.hso + 4 * g;
@@ -242,13 +258,80 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     }
 }
 
-template <int D, int KT>
-static int launch_attn(const AttnParams &p, hipStream_t stream)
+// out[q, :] = sum_s w_s o_s[q, :] / sum_s w_s l_s with w_s = 2^(m_s - max_s m_s): the exact combination of the key ranges' online-softmax
+// states (base-2 exponents as in the kernel).  One thread per (query, 4 channels).
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float *__restrict__ ws_o, const float *__restrict__ ws_ml, bf16_t *__restrict__ out,
+                                                         int heads, int Tq, int D, int ksplit, long long ldo, long long hso, long long total)
 {
-    dim3 grid((unsigned)((p.Tq + 63) / 64), (unsigned)p.heads, (unsigned)p.N);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int d4 = D / 4;
+    const int c = (int)(i % d4);
+    const long long r = i / d4;              // (n * heads + h) * Tq + q
+    const int q = (int)(r % Tq);
+    const long long nh = r / Tq;
+    float m = -INFINITY;
+    for (int s = 0; s < ksplit; ++s) m = fmaxf(m, ws_ml[((nh * ksplit + s) * Tq + q) * 2]);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const long long row = (nh * ksplit + s) * Tq + q;
+        const float w = __builtin_amdgcn_exp2f(ws_ml[row * 2] - m);
+        L += w * ws_ml[row * 2 + 1];
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(ws_o + row * D + c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += w * o[j];
+    }
+    const float inv = 1.0f / L;
+    const int h = (int)(nh % heads);
+    const long long n = nh / heads;
+    bf16x4 ob;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(acc[j] * inv);
+    *reinterpret_cast<bf16x4 *>(out + (n * Tq + q) * ldo + (long long)h * hso + c * 4) = ob;
+}
+
+// Key split for UNDER-FILLED single-head grids (AE mid-block attention: one head of 384 / 512 channels over T = 4096: 64 workgroups, each
+// streaming all 8 MB of K / V at what one CU can take in): split the keys over `ksplit` workgroups so that the grid fills the chip.
+static int attn_ksplit(int D, int KT, long long blocks, int Tkv)
+{
+    if (D < 256 || blocks >= 128 || Tkv < 8 * KT) return 1;
+    int s = (int)(256 / blocks);
+    if (s > 8) s = 8;
+    while (s > 1 && (Tkv + s - 1) / s < 4 * KT) --s;
+    return s < 2 ? 1 : s;
+}
+
+template <int D, int KT>
+static int launch_attn(AttnParams p, const gg_attention_desc *d, hipStream_t stream)
+{
+    const long long qtiles = (p.Tq + 63) / 64, blocks = qtiles * p.heads * p.N;
+    int ks = attn_ksplit(D, KT, blocks, p.Tkv);
+    const long long rows = (long long)p.N * p.heads * ks * p.Tq, need = rows * (D + 2) * 4;
+    if (ks > 1 && (!d->workspace || d->workspace_bytes < need)) ks = 1;          // no workspace: the unsplit kernel (slower, same result)
+    p.ksplit = ks;
+    p.kchunk = ks > 1 ? (int)((((p.Tkv + ks - 1) / ks) + KT - 1) / KT * KT) : p.Tkv;
+    p.ws_o = (float *)d->workspace;
+    p.ws_ml = p.ws_o ? p.ws_o + rows * D : nullptr;
+    dim3 grid((unsigned)(qtiles * ks), (unsigned)p.heads, (unsigned)p.N);
     hipLaunchKernelGGL((attn_kernel<D, KT>), grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
+    if (ks > 1) {
+        const long long total = (long long)p.N * p.heads * p.Tq * (D / 4);
+        hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float *)p.ws_o, (const float *)p.ws_ml,
+                           p.out, p.heads, p.Tq, D, ks, p.ldo, p.hso, total);
+        GG_CHECK_LAUNCH();
+    }
     return GG_OK;
+}
+
+extern "C" int64_t gg_attention_workspace_bytes(const gg_attention_desc *d)
+{
+    if (!d || d->N <= 0 || d->heads <= 0 || d->Tq <= 0 || d->Tkv <= 0) return 0;
+    const int KT = d->head_dim == 32 ? 256 : d->head_dim <= 128 ? 64 : 32;
+    const long long blocks = (long long)((d->Tq + 63) / 64) * d->heads * d->N;
+    const int ks = attn_ksplit(d->head_dim, KT, blocks, d->Tkv);
+    return ks > 1 ? (int64_t)d->N * d->heads * ks * d->Tq * (d->head_dim + 2) * 4 : 0;
 }
 
 extern "C" int gg_attention_forward(const gg_attention_desc *d, void *stream_)
@@ -264,13 +347,14 @@ extern "C" int gg_attention_forward(const gg_attention_desc *d, void *stream_)
     p.ldq = d->ldq; p.hsq = d->hsq; p.ldk = d->ldk; p.hsk = d->hsk; p.ldv = d->ldv; p.hsv = d->hsv; p.ldo = d->ldo; p.hso = d->hso;
     p.scale_log2 = d->scale * 1.4426950408889634f;
     p.q = (const bf16_t *)d->q; p.k = (const bf16_t *)d->k; p.v = (const bf16_t *)d->v; p.out = (bf16_t *)d->out;
+    p.ksplit = 1; p.kchunk = d->Tkv; p.ws_o = nullptr; p.ws_ml = nullptr;
     switch (d->head_dim) {
-        case 32: return launch_attn<32, 256>(p, stream);
-        case 64: return launch_attn<64, 64>(p, stream);
-        case 128: return launch_attn<128, 64>(p, stream);
-        case 256: return launch_attn<256, 32>(p, stream);
-        case 384: return launch_attn<384, 32>(p, stream);
-        case 512: return launch_attn<512, 32>(p, stream);
+        case 32: return launch_attn<32, 256>(p, d, stream);
+        case 64: return launch_attn<64, 64>(p, d, stream);
+        case 128: return launch_attn<128, 64>(p, d, stream);
+        case 256: return launch_attn<256, 32>(p, d, stream);
+        case 384: return launch_attn<384, 32>(p, d, stream);
+        case 512: return launch_attn<512, 32>(p, d, stream);
         default: GG_FAIL(GG_ERR_UNSUPPORTED, "attention: head_dim %d not in {32,64,128,256,384,512}", d->head_dim);
     }
 }

@@ -28,7 +28,7 @@
 #include <atomic>
 #include "gg_conv.h"
 #ifndef GG_BOX_ACC_SILU_MAX_ELEMS
-#define GG_BOX_ACC_SILU_MAX_ELEMS 32768      /* in-image elements of a box up to which a SiLU norm is folded into the conv (A/B: tools/experiments) */
+#define GG_BOX_ACC_SILU_MAX_ELEMS 0          /* elements of a workgroup's box up to which a SiLU norm is folded into the conv (0: never; A/B: tools/experiments) */
 #endif
 #include <stdlib.h>
 
@@ -710,15 +710,18 @@ bool gg_conv_box_emits_stats(const ConvParams &p) { return p.out_dtype != GG_F32
 // Prologue computed from accumulators inside the conv (gg_conv_desc.pro_acc1).  The fold itself is ~0.5 us per workgroup; what decides
 // is the in-place transform, redone by every cout tile that shares a box: an affine-only norm (attention / SpatialTransformer: no
 // SiLU) is a handful of VALU per 16-byte piece and always pays against the ~4.5 us GroupNorm launch it removes; a SiLU norm is
-// transcendental-bound (2 per element) and pays only where few cout tiles share a box (as with external tables) or the in-image part of
-// the box is small (the 4x4 level: <= 64 elements per thread).
+// transcendental-bound (2 per element) and pays only where few cout tiles share a box (as with external tables) or the workgroup's box
+// is small (GG_BOX_ACC_SILU_MAX_ELEMS elements; A/B in tools/experiments/README.md).
 bool gg_conv_box_prologue_from_acc(const ConvParams &p)
 {
     BoxPlan pl;
     if (!plan_box(p, pl) || p.C1 + p.C2 > 2048 || !p.prologue_act) return false;
     if (p.prologue_act == 2) return true;
+    // SiLU norm: what a workgroup pays is the in-place pass over ITS box (rows x input channels, 2 transcendentals per element)
+    const int RPT = 16 / pl.TWI, TH = pl.MT * RPT;
+    const long long rows = p.upsample ? (long long)(TH / 2 + 2) * (pl.TWI / 2 + 2) : (long long)(TH + 2 * (p.kh == 3)) * (pl.TWI + 2 * (p.kw == 3));
     constexpr long long silu_max_elems = GG_BOX_ACC_SILU_MAX_ELEMS;
-    return p.Cout_pad / (16 * pl.CT) <= 2 || (long long)p.H * p.W * (p.C1 + p.C2) <= silu_max_elems;
+    return p.Cout_pad / (16 * pl.CT) <= 2 || rows * (p.C1 + p.C2) <= silu_max_elems;
 }
 
 // Returns GG_ERR_UNSUPPORTED (silently) when the shape is outside the envelope.  stream == (hipStream_t)-1: dry run.

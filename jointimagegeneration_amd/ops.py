@@ -532,6 +532,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     if is_f32(q):                                   # fp32 validation path
         check(lib.gg_attention_forward_f32(C.byref(d), _stream()), "gg_attention_forward_f32")
         return
+    wsb = lib.gg_attention_workspace_bytes(C.byref(d))
+    if wsb > 0:                                     # under-filled single-head grid (AE mid attention): keys split over workgroups
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=q.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
     check(lib.gg_attention_forward(C.byref(d), _stream()), "gg_attention_forward")
 
 

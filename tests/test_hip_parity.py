@@ -609,6 +609,37 @@ def test_attention_legacy_layout(dev, cfg):
     assert rel_err(out.float().permute(0, 2, 1), ref) < 2e-2
 
 
+@pytest.mark.parametrize("cfg", [(1, 1, 512, 4096), (1, 1, 384, 1030), (2, 1, 256, 777)], ids=lambda c: f"N{c[0]}h{c[1]}d{c[2]}T{c[3]}")
+def test_attention_key_split_single_head(dev, cfg):
+    """Under-filled single-head grids (the AE mid-block attention: 64 workgroups at T = 4096) split the KEYS over workgroups and merge the
+    online-softmax states in a second launch (gg_attention_workspace_bytes > 0): same result as the oracle and as the unsplit kernel
+    (no workspace), ragged key ranges and empty trailing ranges included."""
+    import ctypes as C
+    from jointimagegeneration_amd import _lib, ops
+    N, heads, ch, Tn = cfg
+    g = torch.Generator().manual_seed(Tn)
+    qkv = torch.randn(N, heads * 3 * ch, Tn, generator=g) * 0.5
+    ref = O.qkv_attention_legacy(bf(qkv), heads)
+    qcl = qkv.permute(0, 2, 1).contiguous().to(dev).bfloat16()
+    ld = heads * 3 * ch
+    d = _lib.AttentionDesc()
+    d.N, d.heads, d.head_dim, d.Tq, d.Tkv = N, heads, ch, Tn, Tn
+    d.ldq = d.ldk = d.ldv = ld
+    d.hsq = d.hsk = d.hsv = 3 * ch
+    d.ldo, d.hso, d.scale = heads * ch, ch, 1.0 / math.sqrt(ch)
+    assert _lib.load().gg_attention_workspace_bytes(C.byref(d)) > 0
+    out = torch.empty(N, Tn, heads * ch, dtype=torch.bfloat16, device=dev)
+    ops.attention(qcl, qcl, qcl, out, N, heads, ch, Tn, Tn, (ld, 3 * ch), (ld, 3 * ch), (ld, 3 * ch), (heads * ch, ch), 1.0 / math.sqrt(ch),
+                  q_off=0, k_off=ch, v_off=2 * ch)
+    assert rel_err(out.float().permute(0, 2, 1), ref) < 2e-2
+    # unsplit (no workspace handed in): the same numbers up to the order of the fp32 state merges
+    d.q, d.k, d.v = qcl.data_ptr(), qcl.data_ptr() + 2 * ch, qcl.data_ptr() + 4 * ch
+    out1 = torch.empty_like(out)
+    d.out = out1.data_ptr()
+    _lib.check(_lib.load().gg_attention_forward(C.byref(d), torch.cuda.current_stream().cuda_stream), "gg_attention_forward")
+    assert float((out.float() - out1.float()).abs().max()) <= 2.0 ** -6 * float(out1.float().abs().max())
+
+
 def test_attention_cross_context(dev):
     from jointimagegeneration_amd import ops
     g = torch.Generator().manual_seed(3)
