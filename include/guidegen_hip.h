@@ -117,7 +117,16 @@ typedef struct {
     const float *pro_gamma;      /* fp32 [pro_c_logical]                                                   */
     const float *pro_beta;
     float pro_eps;
+    /* Optional K-concatenated 1x1 skip projection of a ResBlock (out = conv3x3(h) + conv1x1(x): unet.py:228-262, openaimodel.py:244-278
+     * `self.skip_connection(x) + h`): the conv takes x (one or two sources, the skip concat) as extra input channels at the centre
+     * tap, so the separate skip-conv launch and the residual read disappear.  skip_weight: the 1x1 weight packed by gg_conv_pack_weight
+     * (ntaps = 1, Cin_pad = skip_C1 + skip_C2); `bias` must already hold conv bias + skip bias; `residual` must be NULL.  Only where
+     * gg_conv_fuses_skip(desc) == 1 (box kernel, 3x3, stride 1, no upsample).  skip_C1 == 0: plain conv. */
+    int32_t skip_C1, skip_C2;    /* channels of skip_src1 / skip_src2 (padded, multiples of 32)             */
     int32_t reserved_tail;
+    const void *skip_src1;       /* bf16 CL [N,D,H,W,skip_C1] (same extent as the conv's input)            */
+    const void *skip_src2;       /* bf16 CL [N,D,H,W,skip_C2] or NULL                                      */
+    const void *skip_weight;
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -138,6 +147,8 @@ int gg_conv_emits_stats(const gg_conv_desc *desc);
 /* 1 if gg_conv_forward(desc) can compute the GroupNorm prologue desc->prologue_act from accumulators (gg_conv_desc.pro_acc1) on its
  * own; pointers are not read. */
 int gg_conv_prologue_from_acc(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) can take desc->skip_C1 / skip_C2 channels of a K-concatenated 1x1 skip projection; pointers are not read. */
+int gg_conv_fuses_skip(const gg_conv_desc *desc);
 /* 1 if gg_conv_forward(desc) can run the fused DDIM epilogue (see gg_conv_desc.ddim_x); pointers are not read. */
 int gg_conv_fuses_ddim(const gg_conv_desc *desc);
 int gg_conv_forward(const gg_conv_desc *desc, void *stream);

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
         ("residual", vp), ("out", vp), ("gn_scale", vp), ("gn_shift", vp), ("workspace", vp), ("workspace_bytes", i64), ("reserved_ptr", vp), ("gn_acc", vp),
         ("ddim_x", vp), ("ddim_scalars", vp), ("ddim_pred_x0", vp), ("ddim_unet_in", vp), ("ddim_unet_in_stride", i64),
         ("epilogue_geglu", i32), ("pro_c_logical", i32), ("pro_acc1", vp), ("pro_acc2", vp), ("pro_gamma", vp), ("pro_beta", vp),
-        ("pro_eps", f32), ("reserved_tail", i32),
+        ("pro_eps", f32), ("skip_C1", i32), ("skip_C2", i32), ("reserved_tail", i32), ("skip_src1", vp), ("skip_src2", vp), ("skip_weight", vp),
     ]
 
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "gg_conv_fuses_prologue": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_emits_stats": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_prologue_from_acc": (C.c_int, [C.POINTER(ConvDesc)]),
+    "gg_conv_fuses_skip": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_fuses_ddim": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_groupnorm_workspace_bytes": (i64, [i32, i64, i32]),
     "gg_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i64, vp]),

@@ -221,15 +221,24 @@ class ResBlock(TimestepBlock):
         cin_pad = h.Cpad + (src2.Cpad if src2 is not None else 0)
         # (running the 1x1 skip projection on a side stream beside the GN -> conv1 -> GN chain was measured slower: the fork / join
         # edges in the hipGraph cost more than the overlap saves, 3.03 vs 2.69 ms per latent-UNet forward)
-        res = h
-        if not isinstance(self.skip_connection, nn.Identity):
-            pws, pbs = packed_conv(self.skip_connection, cin_pad)
-            ks = _k3(self.skip_connection.weight)
-            res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
+        res, skip_kw = h, {}
         pw1, _ = packed_conv(c1, cin_pad)
+        pw2, pb2 = packed_conv(c2, pad32(self.out_channels))
+        sk = self.skip_connection
+        if not isinstance(sk, nn.Identity):
+            pws, pbs = packed_conv(sk, cin_pad)
+            ks = _k3(sk.weight)
+            h1_shape = CL(h.t[..., :1].expand(*h.t.shape[:4], pad32(self.out_channels)), self.out_channels)     # shape carrier for the query (no data read)
+            if ks == (1, 1, 1) and ops.conv_fuses_skip(h1_shape, self.out_channels, h, src2, k=k):
+                # 1x1 skip projection K-concatenated into conv2 (gg_conv_desc.skip_src1): no skip launch, no residual round trip
+                pb_c2 = pb2
+                pb2 = PACKED.get((id(self), "b2s"), [c2.bias, sk.bias], lambda: pb_c2 + pbs)          # conv2 bias + skip bias
+                res, skip_kw = None, {"skip": (h, src2, pws)}
+            else:
+                res = ops.conv(h, pws, pbs, self.out_channels, k=ks, pad=ks[-1] // 2, src2=src2)
         h1 = norm_conv(h, self.in_layers[0], True, pw1, tbias, self.out_channels, src2=src2, k=k, bias_per_sample=True)
-        pw2, pb2 = packed_conv(c2, h1.Cpad)
-        return norm_conv(h1, self.out_layers[0], True, pw2, pb2, self.out_channels, k=k, residual=res, want_stats=want_stats)
+        assert h1.Cpad == pad32(self.out_channels)
+        return norm_conv(h1, self.out_layers[0], True, pw2, pb2, self.out_channels, k=k, residual=res, want_stats=want_stats, **skip_kw)
 
 
 class AttentionBlock(nn.Module):

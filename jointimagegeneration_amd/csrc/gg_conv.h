@@ -28,6 +28,9 @@ struct ConvParams {
     const float *pro_gamma, *pro_beta;
     float pro_eps;
     int pro_clog;
+    // K-concatenated 1x1 skip projection (gg_conv_desc.skip_src1; box kernel, 3x3 stride 1 only)
+    const bf16_t *skip_src1, *skip_src2, *skip_weight;
+    int skip_C1, skip_C2;
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

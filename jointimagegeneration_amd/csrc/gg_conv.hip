@@ -702,6 +702,8 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     p.pro_acc1 = (const long long *)d->pro_acc1; p.pro_acc2 = (const long long *)d->pro_acc2; p.pro_gamma = d->pro_gamma; p.pro_beta = d->pro_beta;
     p.pro_eps = d->pro_eps; p.pro_clog = d->pro_c_logical;
     if (d->gn_scale || d->gn_shift || !d->prologue_act) p.pro_acc1 = p.pro_acc2 = nullptr;          // external tables win; no prologue: unused
+    p.skip_src1 = (const bf16_t *)d->skip_src1; p.skip_src2 = (const bf16_t *)d->skip_src2; p.skip_weight = (const bf16_t *)d->skip_weight;
+    p.skip_C1 = d->skip_C1; p.skip_C2 = d->skip_C2;
     p.mg_osp = gg_magic_u32(p.M, d->Do * d->Ho * d->Wo); p.mg_ohw = gg_magic_u32(p.M, d->Ho * d->Wo); p.mg_wo = gg_magic_u32(p.M, d->Wo);
 }
 
@@ -730,6 +732,18 @@ extern "C" int gg_conv_prologue_from_acc(const gg_conv_desc *d)
     fill_params(d, p);
     if (halo_try_dry(p)) return 0;
     return gg_conv_box_try(p, (hipStream_t)-1) == GG_OK && gg_conv_box_prologue_from_acc(p) ? 1 : 0;
+}
+
+// K-concatenated 1x1 skip projection: box kernel only (3x3, stride 1, no upsample: plan_box checks).
+extern "C" int gg_conv_fuses_skip(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu || d->skip_C1 <= 0 || d->skip_C1 % 32 || d->skip_C2 % 32 ||
+        d->skip_C2 < 0 || d->residual || d->ddim_x)
+        return 0;
+    ConvParams p;
+    fill_params(d, p);
+    if (halo_try_dry(p)) return 0;
+    return gg_conv_box_try(p, (hipStream_t)-1) == GG_OK ? 1 : 0;
 }
 
 // The fused DDIM epilogue lives in the box kernel's epilogue (the latent UNet's head conv at batch 1..4 runs there).
@@ -786,6 +800,10 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
         GG_FAIL(GG_ERR_BAD_SHAPE, "conv: output extent (%d,%d,%d) inconsistent with input (%d,%d,%d) k=(%d,%d,%d) stride %d pad %d up %d",
                 d->Do, d->Ho, d->Wo, d->D, d->H, d->W, d->kd, d->kh, d->kw, d->stride, d->pad, d->upsample);
 
+    if (d->skip_C1) {
+        if (!gg_conv_fuses_skip(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot take a K-concatenated skip projection (gg_conv_fuses_skip)");
+        if (!d->skip_src1 || !d->skip_weight || (d->skip_C2 && !d->skip_src2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: skip projection without source / weight");
+    }
     if (d->ddim_x && !gg_conv_fuses_ddim(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot run the fused DDIM epilogue (gg_conv_fuses_ddim)");
     if (d->ddim_x && (!d->ddim_scalars || (d->ddim_unet_in && d->ddim_unet_in_stride < 4))) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: fused DDIM epilogue needs scalars / a unet_in stride >= 4");
     ConvParams p;

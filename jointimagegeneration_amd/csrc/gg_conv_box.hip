@@ -50,11 +50,11 @@
 // Exact division of small non-negative integers by run-time constants: q = (n * ceil(2^32 / d)) >> 32 for n * d < 2^32 (block ids,
 // k-steps and DMA units are all < 2^16).  One s_mul_hi_u32 instead of the ~30-instruction 32-bit division sequence: at batch 1 the
 // ~520 serially issued instructions between kernel entry and the first DMA were 1.1 us of a 10 us kernel (phase stamps).
-struct BoxMagic { unsigned pq, tw, th, nch, nch_last; int Q; };
+struct BoxMagic { unsigned pq, tw, th, nch, nch_last; int Q; unsigned nch_s, nch_s_last; int nstage_s, nch_stage_s; };
 __device__ __forceinline__ int gg_mdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
 static unsigned gg_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // d == 1: handled by the caller
 
-template <int TWI, int MT, int CT, int UP, int K3>
+template <int TWI, int MT, int CT, int UP, int K3, int SK = 0>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg, const int tiles_h_arg, const int tiles_w_arg, const int nstage_arg,
                                                          const int nch_stage_arg, const int gn_bytes_arg, const int q_major_arg, const int nblocks_arg, const BoxMagic mg_arg)
 {
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     BoxMagic mg;
     mg.pq = gg_pin(mg_arg.pq); mg.tw = gg_pin(mg_arg.tw); mg.th = gg_pin(mg_arg.th); mg.nch = gg_pin(mg_arg.nch);
     mg.nch_last = gg_pin(mg_arg.nch_last); mg.Q = gg_pin(mg_arg.Q);
+    mg.nch_s = mg_arg.nch_s; mg.nch_s_last = mg_arg.nch_s_last; mg.nstage_s = mg_arg.nstage_s; mg.nch_stage_s = mg_arg.nch_stage_s;
     // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
     constexpr int TW = TWI, NW = 8;
     constexpr int RPT = 16 / TWI;
@@ -489,6 +490,110 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         GG_STAMP(5);
     }
 
+    // ---- K-concatenated 1x1 skip projection (gg_conv_desc.skip_src1): out = conv3x3(act(GN(h1))) + conv1x1(x) in ONE launch.  The raw x
+    //      tile of the workgroup's own positions (no halo: TH x TW rows, the 1x1 geometry with the row-based swizzle) is staged into
+    //      the same LDS region in stages of its own after the 3x3 stages, and its k-steps (one per 32-channel chunk) add into the
+    //      same accumulators: the separate skip-conv launch (~6.4 us at batch 1, 18 per latent-UNet forward) and the residual round
+    //      trip of the epilogue are gone; the price is the x tile's bytes into every CU.
+    if constexpr (SK) {
+        constexpr int PLANE1 = MT * 1024;                 // one chunk plane of the tile: MT 16-row blocks
+        constexpr int SPT1 = 3;                           // chunk k-steps per weight trip (reuses the 3x3 ring's shape)
+        const int Cs1 = p.skip_C1, Cs2 = p.skip_C2, nck1 = Cs1 >> 5, nck = (Cs1 + Cs2) >> 5;
+        const int lo1 = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);            // row = 16 * tile + fr: the row-based map only sees fr
+        const bf16_t *wsk = p.skip_weight + ((long long)g * nck << 10) + half * 512;      // [Cout_pad / 32][1 tap][nck][32 co][32 ci]
+        const char *x1n = reinterpret_cast<const char *>(p.skip_src1 + (long long)n * p.H * p.W * Cs1);
+        const char *x2n = reinterpret_cast<const char *>(p.skip_src2 + (long long)n * p.H * p.W * Cs2);
+        for (int st = 0; st < mg.nstage_s; ++st) {
+            const int cbase = st * mg.nch_stage_s;
+            const int nch = (nck - cbase < mg.nch_stage_s) ? nck - cbase : mg.nch_stage_s;
+            const unsigned mnch = nch == mg.nch_stage_s ? mg.nch_s : mg.nch_s_last;
+            const int nunit = nch * MT;
+            const int u0 = (nunit * wave) / NW, u1 = (nunit * (wave + 1)) / NW;
+            {
+                int rbk = mdiv(u0, nch, mnch), c = u0 - rbk * nch;
+                int left = u1 - u0;
+                while (left > 0) {
+                    const int row = rbk * 16 + lrow;
+                    const int hh = row / TW, hw = row - hh * TW;
+                    const int ih = h0 + hh, iw = w0 + hw;
+                    const unsigned pos = (ih < p.H) ? (unsigned)(ih * p.W + iw) : 0u;   // rows past a ragged last tile: any legal address (outputs not stored)
+                    const unsigned q8 = (unsigned)((lslot ^ ((row >> 1) & 2)) * 8);
+                    const unsigned o1 = (pos * (unsigned)Cs1 + q8) * 2u, o2 = (pos * (unsigned)Cs2 + q8) * 2u;
+                    int run = nch - c < left ? nch - c : left;
+                    left -= run;
+                    const int gc = cbase + c;
+                    char *dst = box + c * PLANE1 + rbk * 1024;
+                    int n1 = nck1 - gc;
+                    n1 = n1 < 0 ? 0 : (n1 > run ? run : n1);
+                    const char *sb = x1n + gc * 64;
+#pragma unroll 2
+                    for (int i = 0; i < n1; ++i) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + o1),
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                        sb += 64;
+                        dst += PLANE1;
+                    }
+                    sb = x2n + (gc + n1 - nck1) * 64;
+#pragma unroll 2
+                    for (int i = n1; i < run; ++i) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + o2),
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                        sb += 64;
+                        dst += PLANE1;
+                    }
+                    c = 0;
+                    ++rbk;
+                }
+            }
+            // weight stream: this wave's chunks [q0, q1), three per trip, straight from L2 into VGPRs (as the 3x3 stages)
+            const int q0 = (nch * wave) / NW, q1 = (nch * (wave + 1)) / NW;
+            int lc = q0;
+            bf16x8 ws[2][SPT1][CT];
+            auto load_ws = [&](bf16x8 (&a)[SPT1][CT]) {
+#pragma unroll
+                for (int u = 0; u < SPT1; ++u) {
+                    const bf16_t *tile = wsk + ((long long)(cbase + lc) << 10) + wl0;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                    lc += (lc + 1 < q1) ? 1 : 0;
+                }
+            };
+            asm volatile("" ::: "memory");                 // keep the weight loads behind the DMA issue
+            load_ws(ws[0]);
+            load_ws(ws[1]);
+            __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(2 * SPT1 * CT));      // this wave's DMAs have landed
+            GG_BOX_LDS_BARRIER();
+            int cc = q0;
+            auto trip_s = [&](const bf16x8 (&a)[SPT1][CT], int q) {
+#pragma unroll
+                for (int u = 0; u < SPT1; ++u)
+                    if (q + u < q1) {
+                        const char *pa = box + cc * PLANE1 + lo1;
+                        bf16x8 xf[MT];
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt) xf[tt] = *reinterpret_cast<const bf16x8 *>(pa + tt * 1024);
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct)
+                                acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][ct], xf[tt], acc[tt][ct], 0, 0, 0);
+                        ++cc;
+                    }
+            };
+            int q = q0;
+#pragma unroll 1
+            for (; q + 2 * SPT1 < q1; q += 2 * SPT1) {
+                trip_s(ws[0], q);
+                load_ws(ws[0]);
+                trip_s(ws[1], q + SPT1);
+                load_ws(ws[1]);
+            }
+            trip_s(ws[0], q);
+            trip_s(ws[1], q + SPT1);
+            GG_BOX_WAIT_BARRIER(0);
+        }
+    }
+
     // ---- combine the 8 waves (fixed order), then bias / residual / store.  red[wave][tt][ct][lane] is lane-contiguous:
     //      conflict-free 1 KiB wave writes and reads.
     // the thread's residual values of the final pass are requested now, a barrier and the 8-wave combine ahead of their use
@@ -591,7 +696,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     GG_STAMP(7);
 }
 
-struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; };
+struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; int nstage_s, nch_stage_s; };
 
 // Cost model: bytes one CU has to take in (its weight slice + its input box), times the number of rounds the grid needs on
 // 256 CUs.  Smallest wins; ties go to the larger tile (fewer redundant halo bytes overall).
@@ -648,11 +753,21 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     const long long P = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI), Q = p.Cout_pad / (16 * CT);
     const long long wtot = wbytes16 * (p.Cout_pad / 16), xtot = (long long)p.N * p.H * p.W * p.nchunk * 64;
     const long long cost_q = wtot + xtot * (Q < 8 ? Q : 8), cost_p = wtot * (P < 8 ? P : 8) + xtot;
-    pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes};
+    // K-concatenated 1x1 skip projection: stages of the x tile (MT KiB per chunk) in the same region
+    int nstage_s = 0, nch_stage_s = 0;
+    if (p.skip_C1 > 0) {
+        if (!k3 || p.upsample || p.skip_C1 % 32 || p.skip_C2 % 32) return false;
+        const long long plane1 = (long long)MT * 1024, nck = (p.skip_C1 + p.skip_C2) / 32;
+        const long long cap1 = lds_cap / plane1;
+        nstage_s = (int)((nck + cap1 - 1) / cap1);
+        nch_stage_s = (int)((nck + nstage_s - 1) / nstage_s);
+        if (smem < nch_stage_s * plane1) smem = nch_stage_s * plane1;
+    }
+    pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes, nstage_s, nch_stage_s};
     return true;
 }
 
-template <int TWI, int MT, int CT, int UP, int K3>
+template <int TWI, int MT, int CT, int UP, int K3, int SK = 0>
 static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     // the attribute is per device: one bit per device ordinal (setting it twice from two threads is harmless)
@@ -661,7 +776,7 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     if (hipGetDevice(&dev) != hipSuccess) return GG_ERR_HIP;
     const unsigned long long dev_bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_mask.fetch_or(dev_bit, std::memory_order_release);
     }
@@ -669,27 +784,29 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
     const int Pn = p.N * tiles_h * tiles_w, Qn = p.Cout_pad / (16 * CT);
     const int nch_last = p.nchunk - (pl.nstage - 1) * pl.nch_stage;
-    const BoxMagic mg = {gg_magic(pl.q_major ? Pn : Qn), gg_magic(tiles_w), gg_magic(tiles_h), gg_magic(pl.nch_stage), gg_magic(nch_last), Qn};
-    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
+    const int nck_s = (p.skip_C1 + p.skip_C2) / 32, nch_s_last = pl.nstage_s ? nck_s - (pl.nstage_s - 1) * pl.nch_stage_s : 0;
+    const BoxMagic mg = {gg_magic(pl.q_major ? Pn : Qn), gg_magic(tiles_w), gg_magic(tiles_h), gg_magic(pl.nch_stage), gg_magic(nch_last), Qn,
+                         gg_magic(pl.nch_stage_s), gg_magic(nch_s_last), pl.nstage_s, pl.nch_stage_s};
+    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3, SK>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
                        pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x, mg);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
 
-template <int CT, int UP, int K3>
+template <int CT, int UP, int K3, int SK = 0>
 static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     switch (pl.TWI * 10 + pl.MT) {
-        case 172: return launch_box<16, 12, CT, UP, K3>(p, pl, stream);
-        case 168: return launch_box<16, 8, CT, UP, K3>(p, pl, stream);
-        case 166: return launch_box<16, 6, CT, UP, K3>(p, pl, stream);
-        case 163: return launch_box<16, 3, CT, UP, K3>(p, pl, stream);
-        case 164: return launch_box<16, 4, CT, UP, K3>(p, pl, stream);
-        case 162: return launch_box<16, 2, CT, UP, K3>(p, pl, stream);
-        case 84: return launch_box<8, 4, CT, UP, K3>(p, pl, stream);
-        case 82: return launch_box<8, 2, CT, UP, K3>(p, pl, stream);
-        case 81: return launch_box<8, 1, CT, UP, K3>(p, pl, stream);
-        case 41: return launch_box<4, 1, CT, UP, K3>(p, pl, stream);
+        case 172: return launch_box<16, 12, CT, UP, K3, SK>(p, pl, stream);
+        case 168: return launch_box<16, 8, CT, UP, K3, SK>(p, pl, stream);
+        case 166: return launch_box<16, 6, CT, UP, K3, SK>(p, pl, stream);
+        case 163: return launch_box<16, 3, CT, UP, K3, SK>(p, pl, stream);
+        case 164: return launch_box<16, 4, CT, UP, K3, SK>(p, pl, stream);
+        case 162: return launch_box<16, 2, CT, UP, K3, SK>(p, pl, stream);
+        case 84: return launch_box<8, 4, CT, UP, K3, SK>(p, pl, stream);
+        case 82: return launch_box<8, 2, CT, UP, K3, SK>(p, pl, stream);
+        case 81: return launch_box<8, 1, CT, UP, K3, SK>(p, pl, stream);
+        case 41: return launch_box<4, 1, CT, UP, K3, SK>(p, pl, stream);
         default: return GG_ERR_UNSUPPORTED;
     }
 }
@@ -730,6 +847,7 @@ int gg_conv_box_try(const ConvParams &p, hipStream_t stream)
     BoxPlan pl;
     if (!plan_box(p, pl)) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
+    if (p.skip_C1 > 0) return pl.CT == 2 ? dispatch_box<2, 0, 1, 1>(p, pl, stream) : dispatch_box<1, 0, 1, 1>(p, pl, stream);     // (plan_box: 3x3, no upsample)
     if (p.kh == 1) return pl.CT == 2 ? dispatch_box<2, 0, 0>(p, pl, stream) : dispatch_box<1, 0, 0>(p, pl, stream);
     if (pl.CT == 2) return p.upsample ? dispatch_box<2, 1, 1>(p, pl, stream) : dispatch_box<2, 0, 1>(p, pl, stream);
     return p.upsample ? dispatch_box<1, 1, 1>(p, pl, stream) : dispatch_box<1, 0, 1>(p, pl, stream);

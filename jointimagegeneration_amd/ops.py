@@ -222,6 +222,30 @@ def conv_prologue_from_acc(src1: CL, cout: int, act: bool, k=(1, 3, 3), stride: 
     return bool(lib.gg_conv_prologue_from_acc(C.byref(d)))
 
 
+SKIP_KCONCAT = True                 # ResBlock 1x1 skip projections K-concatenated into conv2 where gg_conv_fuses_skip says so (A/B switch)
+
+
+def conv_fuses_skip(src1: CL, cout: int, skip1: CL, skip2: Optional[CL] = None, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
+                    **_ignored) -> bool:
+    """True if this conv (input src1, no second source) can take a K-concatenated 1x1 skip projection of cat[skip1, skip2]
+    (gg_conv_desc.skip_src1): box kernel, 3x3, stride 1."""
+    if not SKIP_KCONCAT or is_f32(src1.t) or (skip2 is not None and skip1.C != skip1.Cpad):
+        return False
+    lib = _lib.load()
+    N, D, H, W, C1 = src1.t.shape
+    Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
+    d = ConvDesc()
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = C1, 0
+    d.Cout, d.Cout_pad = cout, pad32(cout)
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.skip_C1, d.skip_C2 = skip1.Cpad, (skip2.Cpad if skip2 is not None else 0)
+    d.path_hint = PATH_HINT
+    return bool(lib.gg_conv_fuses_skip(C.byref(d)))
+
+
 def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
                         src2: Optional[CL] = None, **_ignored) -> bool:
     """True if this conv runs on the halo-tile kernel (GroupNorm prologue applied once per element while staging)."""
@@ -287,8 +311,9 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
          out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None, geglu: bool = False, prologue_acc: Optional[tuple] = None,
-         want_stats: bool = False) -> CL:
-    """prologue_acc = (gamma, beta, eps): GroupNorm prologue computed inside the conv from src1.acc / src2.acc (conv_prologue_from_acc);
+         want_stats: bool = False, skip: Optional[tuple] = None) -> CL:
+    """skip = (x1: CL, x2: CL or None, packed 1x1 weight): K-concatenated skip projection (conv_fuses_skip; `bias` must include its bias);
+    prologue_acc = (gamma, beta, eps): GroupNorm prologue computed inside the conv from src1.acc / src2.acc (conv_prologue_from_acc);
     want_stats: leave the output's GroupNorm sums behind whatever its size (the consumer will fold them itself);
     ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
     runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step."""
@@ -336,6 +361,10 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         d.pro_acc1 = src1.acc.data_ptr()
         d.pro_acc2 = src2.acc.data_ptr() if src2 is not None else None
         d.pro_c_logical = src1.C + (src2.C if src2 is not None else 0)
+    if skip is not None:
+        d.skip_src1, d.skip_C1 = skip[0].t.data_ptr(), skip[0].Cpad
+        d.skip_src2, d.skip_C2 = (skip[1].t.data_ptr(), skip[1].Cpad) if skip[1] is not None else (None, 0)
+        d.skip_weight = skip[2].data_ptr()
     d.path_hint = PATH_HINT
     d.src1 = t1.data_ptr()
     d.src2 = _ptr(src2.t) if src2 is not None else None

@@ -1124,3 +1124,34 @@ def test_conv_groupnorm_prologue_from_accumulators(dev, cfg, monkeypatch):
         assert rel_err(got, ops.from_cl(old, 2).cpu()) < 1e-2
     finally:
         ops.stats_end(dev)
+
+
+@pytest.mark.parametrize("cfg", [(1, 160, 160, 160, (64, 64)), (1, 640, 640, 640, (16, 16)), (2, 320, 640, 0, (8, 8)), (1, 800, 800, 800, (4, 4)),
+                                 (1, 320, 160, 160, (32, 32)), (1, 64, 96, 0, (20, 16))],
+                         ids=["out64_160+160", "out16_640+640_two_stage_skip", "in8_320_n2", "out4_800+800", "out32_160+160", "ragged_20x16"])
+def test_conv_box_kconcat_skip_projection(dev, cfg):
+    """gg_conv_desc.skip_src1: out = conv3x3(a) + conv1x1(cat[x1, x2]) + (b + bs) in ONE box-kernel launch (ResBlock conv2 with its
+    skip_connection, unet.py:228-262 / openaimodel.py:244-278), vs the oracle and vs the two-launch form (skip conv, then conv2 with the
+    residual), one and two skip sources, several LDS stages of the x tile, a ragged last row tile."""
+    from jointimagegeneration_amd import ops
+    N, Cout, C1, C2, sp = cfg
+    g = torch.Generator().manual_seed(Cout + C1 + C2 + sp[0])
+    a = torch.randn((N, Cout) + sp, generator=g)
+    x1 = torch.randn((N, C1) + sp, generator=g)
+    x2 = torch.randn((N, C2) + sp, generator=g) if C2 else None
+    w = torch.randn(Cout, Cout, 3, 3, generator=g) / math.sqrt(Cout * 9)
+    wsk = torch.randn(Cout, C1 + C2, 1, 1, generator=g) / math.sqrt(C1 + C2)
+    b, bs = 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    acl, x1cl = ops.to_cl(a.to(dev)), ops.to_cl(x1.to(dev))
+    x2cl = ops.to_cl(x2.to(dev)) if C2 else None
+    assert ops.conv_fuses_skip(acl, Cout, x1cl, x2cl, k=(1, 3, 3))
+    pw = ops.pack_conv_weight(w.to(dev), acl.Cpad)
+    pws = ops.pack_conv_weight(wsk.to(dev), x1cl.Cpad + (x2cl.Cpad if C2 else 0))
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    ref = O.conv(bf(a), bf(w), b, padding=1) + O.conv(bf(xin), bf(wsk), bs)
+    got = ops.conv(acl, pw, ops.pad_bias((b + bs).to(dev), Cout, dev), Cout, k=(1, 3, 3), skip=(x1cl, x2cl, pws))
+    assert rel_err(ops.from_cl(got, 2), ref) < 1.2e-2, rel_err(ops.from_cl(got, 2), ref)
+    res = ops.conv(x1cl, pws, ops.pad_bias(bs.to(dev), Cout, dev), Cout, k=(1, 1, 1), pad=0, src2=x2cl)
+    two = ops.conv(acl, pw, ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1, 3, 3), residual=res)
+    # the two-launch form rounds the skip projection to bf16 before adding it: the fused form is the more accurate one
+    assert rel_err(ops.from_cl(got, 2), ops.from_cl(two, 2).cpu()) < 1.2e-2
