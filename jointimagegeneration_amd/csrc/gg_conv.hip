@@ -534,8 +534,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
         long long m = i / q4;
         int co = (int)(i - m * q4) * 4;
         long long o = m * p.Cout_pad + co;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(p.ws + o);
-        for (int z = 1; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4 *>(p.ws + (long long)z * p.M * p.Cout_pad + o);
+        // the slabs of a batch are requested together (one round trip per 16 slabs instead of one per few: the kernel is a chain of
+        // dependent L2 round trips at batch 1), then added in slab order: the sum is the same, bit for bit
+        constexpr int ZB = 16;
+        const long long zs = p.M * p.Cout_pad;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < p.splitk; z0 += ZB) {
+            f32x4 t[ZB];
+#pragma unroll
+            for (int k = 0; k < ZB; ++k) {
+                t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (z0 + k < p.splitk) t[k] = *reinterpret_cast<const f32x4 *>(p.ws + (long long)(z0 + k) * zs + o);
+            }
+#pragma unroll
+            for (int k = 0; k < ZB; ++k) v += t[k];
+        }
         if (p.bias) {
             int n = (int)(m / osp);
             v += *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co);

@@ -27,6 +27,9 @@
 //     (activation-heavy layers) run on the same XCD and hit its L2 (blockIdx round-robins over the 8 XCDs).
 #include <atomic>
 #include "gg_conv.h"
+#ifndef GG_BOX_K1_MAX_M_ACC
+#define GG_BOX_K1_MAX_M_ACC 256
+#endif
 #ifndef GG_BOX_ACC_SILU_MAX_ELEMS
 #define GG_BOX_ACC_SILU_MAX_ELEMS 0          /* elements of a workgroup's box up to which a SiLU norm is folded into the conv (0: never; A/B: tools/experiments) */
 #endif
@@ -708,7 +711,9 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     const int halo = k3 ? 2 : 0;
     // 1x1: only where the grid is under-filled (measured: 8x8 4.2 vs 8.6 us on the tiny-M kernel, but 64x64 12.0 vs 7.8 us on gather5)
     constexpr long long k1_max_m = 256;
-    if (k1 && p.M > k1_max_m) return false;
+    // ... unless the conv folds a GroupNorm from accumulators itself: then the box kernel also replaces the norm's launch
+    const long long k1_lim = (p.prologue_act && p.pro_clog > 0) ? GG_BOX_K1_MAX_M_ACC : k1_max_m;
+    if (k1 && p.M > k1_lim) return false;
     const int TWI = p.Wo % 16 == 0 ? 16 : p.Wo % 8 == 0 ? 8 : p.Wo % 4 == 0 ? 4 : 0;   // width of a 16-position MFMA tile
     if (!TWI) return false;
     const int RPT = 16 / TWI;
