@@ -1157,3 +1157,44 @@ def test_conv_box_kconcat_skip_projection(dev, cfg):
     two = ops.conv(acl, pw, ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1, 3, 3), residual=res)
     # the two-launch form rounds the skip projection to bf16 before adding it: the fused form is the more accurate one
     assert rel_err(ops.from_cl(got, 2), ops.from_cl(two, 2).cpu()) < 1.2e-2
+
+
+def test_dynamic_lds_attribute_is_set_per_device(dev):
+    """the MaxDynamicSharedMemorySize attribute of the 1024-position halo kernel (124 KiB) and of the box kernel is set per
+    device ordinal, not once per process: a conv on a second visible device must launch.  Skipped on one-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(5)
+    outs = []
+    for d in (torch.device("cuda:0"), torch.device("cuda:1")):
+        with torch.cuda.device(d):
+            x = ops.to_cl(torch.randn(1, 32, 8, 8, 16, generator=torch.Generator().manual_seed(5)).to(d))
+            w = torch.randn(32, 32, 3, 3, 3, generator=torch.Generator().manual_seed(6)).to(d) / 30.0
+            import jointimagegeneration_amd.ops as O2
+            old = O2.PATH_HINT
+            O2.PATH_HINT = 6                                   # the 1024-position box (dynamic LDS above the default limit)
+            try:
+                y = ops.conv(x, ops.pack_conv_weight(w, 32), None, 32, k=(3, 3, 3))
+            finally:
+                O2.PATH_HINT = old
+            torch.cuda.synchronize(d)
+            outs.append(y.t.float().cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_invalidate_caches_after_data_writes(dev):
+    """writes through `p.data` (as the reference's ema.py does) bypass the version counter that keys the repacked-weight
+    caches; `ops.invalidate_caches(module)` makes the next forward repack."""
+    from jointimagegeneration_amd import ops
+    from jointimagegeneration_amd.unet import UNetModel
+    u = seeded(UNetModel(**LDM_SMALL), "ldm_small.").to(dev)
+    g = torch.Generator().manual_seed(1)
+    x, t = torch.randn(1, 8, 16, 16, generator=g).to(dev), torch.tensor([481], device=dev)
+    y0 = u(x, t)
+    with torch.no_grad():
+        u.out[2].weight.data.mul_(2.0)                          # invisible to p._version
+        u.out[2].bias.data.mul_(2.0)
+    ops.invalidate_caches(u)
+    y1 = u(x, t)
+    assert float((y1 - 2.0 * y0).abs().max()) <= 2e-2 * float(y1.abs().max())      # head conv is linear in its weights
