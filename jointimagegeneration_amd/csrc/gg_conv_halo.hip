@@ -19,19 +19,35 @@
 #ifndef GG_HALO_G3_2D
 #define GG_HALO_G3_2D 1        /* the same for the 2-D kernel at NT >= 3 (AE convs; same-box A/B: decode 4.137 -> 4.05 ms, cond-encode 1.79 -> 1.75 ms) */
 #endif
+#ifndef GG_HALO_W16_2D
+#define GG_HALO_W16_2D 1
+#endif
+#ifndef GG_HALO_W16_3D
+#define GG_HALO_W16_3D 0
+#endif
+#define GG_HALO_W16(D3, NT, HB) ((GG_HALO_W16_2D && !(D3) && (NT) >= 3) || (GG_HALO_W16_3D && (D3) && ((HB) == 2 || (NT) >= 3)))
+#ifndef GG_HALO_DMA_UPPER
+#define GG_HALO_DMA_UPPER 0
+#endif
+#ifndef GG_HALO_PRIO_UPPER
+#define GG_HALO_PRIO_UPPER 0
+#endif
 #ifndef GG_HALO_WPS
 #define GG_HALO_WPS(NT) 2      /* measured: 4 waves/SIMD forces scratch spills (NT=2) and is not faster */
 #endif
 
 template <int D3, int NT, int UP, int HB>
-__global__ __launch_bounds__(((NT <= 2 && HB != 2) ? 256 : 512), (HB == 1 ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+__global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), (GG_HALO_W16(D3, NT, HB) ? 4 : HB == 1 ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
     // HB 0: 512-position box 4x8x16 (2-D: 1x32x16); 1: 256 positions 4x4x16 (under-filled 3-D grids); 2: 1024 positions 8x8x16, one
     // 8-wave workgroup per CU (halo redundancy 1.76x instead of 2.1x: less staging work per output)
     constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
     // NT <= 2: 4 waves x 8 position-tiles (128 pos x 32*NT couts per wave, 2 workgroups per CU overlap staging and MFMA);
     // NT >= 3: 8 waves x 4 position-tiles (the accumulator would not fit otherwise)
-    constexpr int NWAVE = (NT <= 2 && HB != 2) ? 4 : 8;
+    // 2-D, NT >= 3 (AE convs at 512^2 / 256^2: 9 taps per staged chunk, one workgroup per CU): 16 waves x 2 position tiles = 4 waves per SIMD
+    // at <= 64 accumulator registers each, so that staging round trips and operand reads of one wave hide behind the others' MFMAs
+    // (same-box A/B at NT 4: AE decode 3.75 -> 3.60-3.68 ms)
+    constexpr int NWAVE = GG_HALO_W16(D3, NT, HB) ? 16 : (NT <= 2 && HB != 2) ? 4 : 8;
     constexpr int TPW = (TD * TH) / NWAVE;
     constexpr int NTHR = NWAVE * 64;
     constexpr int KD = D3 ? 3 : 1;
@@ -104,10 +120,13 @@ __global__ __launch_bounds__(((NT <= 2 && HB != 2) ? 256 : 512), (HB == 1 ? 3 : 
     auto issue_w = [&](int ks, int buf) {               // ks: tap index (GSZ == 1) or index of the first tap of a line (GSZ == 3)
         const int chunk = ks / NTAPS, tap0 = ks - chunk * NTAPS;
         constexpr int NP = GSZ * NT * 2;                // 1 KiB pieces of the slot
+        // GG_HALO_DMA_UPPER: only the upper half of the waves (the SIMD partners of waves 0 .. NWAVE/2-1) issue the weight DMAs, so the
+        // two waves of a SIMD are not in lockstep after the barrier: one starts its operand reads at once, the other a few DMAs later
+        constexpr int DW = (GG_HALO_DMA_UPPER && G3) ? NWAVE / 2 : NWAVE, DW0 = NWAVE - DW;
 #pragma unroll
-        for (int i = 0; i < (NP + NWAVE - 1) / NWAVE; ++i) {
-            const int piece = wave + NWAVE * i;
-            if (piece < NP) {
+        for (int i = 0; i < (NP + DW - 1) / DW; ++i) {
+            const int piece = (wave - DW0) + DW * i;
+            if (wave >= DW0 && piece < NP) {
                 const int u = piece / (NT * 2), piece1k = piece - u * (NT * 2);
                 const int g = piece1k >> 1, half = piece1k & 1;
                 const bf16_t *src = p.weight + ((((long long)(g0 + g) * NTAPS + tap0 + u) * p.nchunk + chunk) << 10) + half * 512 + lane * 8;
@@ -118,6 +137,7 @@ __global__ __launch_bounds__(((NT <= 2 && HB != 2) ? 256 : 512), (HB == 1 ? 3 : 
     };
 
     const int KS = p.nchunk * NTAPS;
+    if (GG_HALO_PRIO_UPPER && G3 && wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     issue_w(0, 0);
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
@@ -327,7 +347,7 @@ static int launch_halo(const ConvParams &p, hipStream_t stream)
     }
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3((NT <= 2 && HB != 2) ? 256 : 512), LDSB, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3(GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), LDSB, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
