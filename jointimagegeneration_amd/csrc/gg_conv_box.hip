@@ -612,11 +612,32 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             resv[kk] = *reinterpret_cast<const u32x2 *>(p.residual + (((long long)n * p.Ho + oh) * p.Wo + (w0 + (i & 15) % TWI)) * p.Cout_pad + co_thr);
     }
     f32x4 *red = reinterpret_cast<f32x4 *>(box);
+    // MT * CT > 16 (12 position tiles x 2 cout tiles: the 320 -> 320 upsample conv to 64x64 on 240 instead of 480 workgroups): eight slabs
+    // would not fit the LDS, so waves 4-7 ADD their accumulators into the slabs of waves 0-3 in a second phase (fixed order)
+    constexpr bool TWO_PHASE = MT * CT > 16;
+    constexpr int NWR = TWO_PHASE ? 4 : NW;
+    if constexpr (!TWO_PHASE) {
 #pragma unroll
-    for (int tt = 0; tt < MT; ++tt)
+        for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
-    GG_BOX_LDS_BARRIER();
+            for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
+        GG_BOX_LDS_BARRIER();
+    } else {
+        if (wave < 4) {
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) red[((wave * MT + tt) * CT + ct) * 64 + lane] = acc[tt][ct];
+        }
+        GG_BOX_LDS_BARRIER();
+        if (wave >= 4) {
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) red[(((wave - 4) * MT + tt) * CT + ct) * 64 + lane] += acc[tt][ct];
+        }
+        GG_BOX_LDS_BARRIER();
+    }
     GG_STAMP(6);
     const bool stats = p.gn_acc && p.out_dtype != GG_F32;       // GroupNorm statistics of the NEXT norm (see gg_conv_desc.gn_acc)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -626,7 +647,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         if (i >= MT * CT * 64) break;
         f32x4 a = red[i];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) a += red[w * MT * CT * 64 + i];
+        for (int w = 1; w < NWR; ++w) a += red[w * MT * CT * 64 + i];
         const int l = i & 63, tt = (i >> 6) / CT;
         a += bias4;
         const int oh = h0 + tt * RPT + (l & 15) / TWI;
@@ -731,7 +752,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             const long long blocks = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
-            if (blocks > max_blocks || 8LL * MT * CT * 1024 > lds_cap) continue;      // grid cap; the 8-wave combine area must fit
+            if (blocks > max_blocks || (MT * CT > 16 ? 4LL : 8LL) * MT * CT * 1024 > lds_cap) continue;      // grid cap; the combine area (8 slabs, or 4 in two phases) must fit
             // every extra LDS stage is another exposed staging round trip
             const long long plane_c = (long long)((rows + 15) / 16) * 1024;
             const long long cap_c = lds_cap / plane_c > 0 ? lds_cap / plane_c : 1;
@@ -750,7 +771,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     if (TWI == 4 && nstage > 1) return false;                        // 4x4 levels with > 1 stage: the split-K tiny kernel fills more CUs
     const int nch_stage = (p.nchunk + nstage - 1) / nstage;
     long long smem = nch_stage * plane;
-    const long long red = 8LL * MT * CT * 64 * 16;                   // [wave][tt][ct][lane] f32x4
+    const long long red = (MT * CT > 16 ? 4LL : 8LL) * MT * CT * 64 * 16;      // [wave][tt][ct][lane] f32x4 (two-phase combine above 16 tiles)
     if (smem < red) smem = red;
     // scale / shift rows in front of the box: external tables are DMA'd per stage, the accumulator fold keeps all chunks of the conv
     const int gn_bytes = p.prologue_act ? ((p.pro_acc1 ? p.nchunk : nch_stage) * 32 * 8 + 1023) / 1024 * 1024 : 0;
