@@ -396,13 +396,14 @@ def main():
         if not args.no_roofline:
             log("roofline legs (HIP events)")
             line_extra["roofline"] = conv_roofline(pipe, device)
-        if not args.no_roofline and not args.no_extra:
+        # single-GPU characterisation legs (~50 s): only at N = 1, so that in a multi-rank run no rank waits for rank 0 in a barrier
+        if not args.no_roofline and not args.no_extra and world == 1:
             log("roofline legs of the configurations off the C5 wall (SpatialTransformer UNet, pixel-space UNet)")
             try:
                 line_extra["other_stages"] = other_config_stages(device)
             except Exception as e:                                           # never lose the line to an auxiliary leg
                 line_extra["other_stages"] = {"error": repr(e)}
-        if args.volumes_per_gpu == 1 and not args.no_extra and args.max_slices is None:
+        if args.volumes_per_gpu == 1 and not args.no_extra and args.max_slices is None and world == 1:
             log("secondary leg: 8 volumes per GPU (bounded sample)")
             try:
                 line_extra["extra"] = {"volumes_per_gpu_8": batch8_sample(pipe, args)}
