@@ -9,7 +9,7 @@ fixed-shape step is captured in a hipGraph (torch.cuda.CUDAGraph) and replayed w
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, List, Optional, Sequence, Tuple, Union, cast
+from typing import Any, Dict, List, Optional, Sequence, Tuple, cast
 
 import numpy as np
 import torch

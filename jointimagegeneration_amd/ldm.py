@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .blocks import AEDownsample, AEUpsample, AttnBlock2d, Normalize, ResnetBlock, gn_silu, norm_conv, packed_conv
+from .blocks import AEDownsample, AEUpsample, AttnBlock2d, Normalize, ResnetBlock, norm_conv, packed_conv
 from .config import instantiate_from_config
 from .ops import CL, pad32
 

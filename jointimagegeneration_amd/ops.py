@@ -6,10 +6,7 @@ with zero pad lanes, plus the logical channel count.
 """
 from __future__ import annotations
 
-import os
-
 import ctypes as C
-import math
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 

@@ -16,7 +16,7 @@ import torch
 from . import ops
 from .ccdm import DenoisingModel, DiffusionModel
 from .ldm import DDIMSampler, LatentDiffusion
-from .ops import CL, pad32
+from .ops import CL
 from .synth import randomize_parameters
 from .unet import create_unet_openai
 
