@@ -33,6 +33,9 @@
 #ifndef GG_BOX_ACC_SILU_MAX_ELEMS
 #define GG_BOX_ACC_SILU_MAX_ELEMS 0          /* elements of a workgroup's box up to which a SiLU norm is folded into the conv (0: never; A/B: tools/experiments) */
 #endif
+#ifndef GG_BOX_COUT_SUBSPLIT
+#define GG_BOX_COUT_SUBSPLIT 1               /* 3x3 convs of the 8x8 / 4x4 levels: 2 or 4 workgroups per 16-cout tile (A/B: tools/experiments) */
+#endif
 #include <stdlib.h>
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14), as builtins so that the
@@ -57,7 +60,7 @@ struct BoxMagic { unsigned pq, tw, th, nch, nch_last; int Q; unsigned nch_s, nch
 __device__ __forceinline__ int gg_mdiv(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
 static unsigned gg_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // d == 1: handled by the caller
 
-template <int TWI, int MT, int CT, int UP, int K3, int SK = 0>
+template <int TWI, int MT, int CT, int UP, int K3, int SK = 0, int NS = 1>
 __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg, const int tiles_h_arg, const int tiles_w_arg, const int nstage_arg,
                                                          const int nch_stage_arg, const int gn_bytes_arg, const int q_major_arg, const int nblocks_arg, const BoxMagic mg_arg)
 {
@@ -81,7 +84,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // bound, so weight tiles requested early only delay the landing of the box, i.e. the start of the k-loop.
     // A deeper ring topped up AFTER the box has landed (6 / 4 trips, host-gated to shares that fill it) is slower too (1648 vs 1606 us):
     // the phase stamps show the k-loop at the same 3.5-3.8 us either way, i.e. it is not a latency chain but the same intake bound.
-    constexpr int NTRIP = 2;        // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
+    // Cout sub-split: a weight load instruction moves 1 / NS of the bytes, so the ring is NS times deeper for the same bytes in flight
+    // (phase stamps of the 800 -> 800 conv at 4x4: 50 workgroups x 230 KB and 200 x 58 KB both take ~8 us entry to end -- 1.7 us to
+    // the first DMA, ~2.8 us until the box has landed, ~2 us of k-loop, 1.2 us of combine and epilogue; the split buys ~0.5 us).
+    constexpr int NTRIP = 2 * NS;   // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
@@ -117,7 +123,16 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // (divisors of 1 have magic 0: the quotient is the dividend)
     auto mdiv = [](int a, int d, unsigned m) { return d == 1 ? a : gg_mdiv(a, m); };
     const int vq = mdiv(v, q_major ? P : Q, mg.pq);                     // v / P (cout-major) or v / Q (position-major)
-    const int by = q_major ? vq : v - vq * Q;
+    int by = q_major ? vq : v - vq * Q;
+    // Cout sub-split (NS 2 / 4, weight-bound 3x3 convs of the 8x8 / 4x4 levels): NS workgroups share a 16-cout tile and take 16 / NS of
+    // its weight rows each (the other lanes' operand registers are zeros: no load), so the level's weight stream spreads over 4x the
+    // CUs without a cross-workgroup reduction; each stores (and adds the GroupNorm sums of) its own couts only.
+    static_assert(NS == 1 || (CT == 1 && (NS == 2 || NS == 4)), "cout sub-split: single cout tile, 2 or 4 ways");
+    constexpr int CSZ = 16 / NS;
+    const int sub = by & (NS - 1);
+    by >>= (NS == 4 ? 2 : NS == 2 ? 1 : 0);
+    const bool wact = NS == 1 || (fr / CSZ) == sub;                       // this lane's weight row belongs to the workgroup
+    const bool oact = NS == 1 || (((lane >> 4) * 4) / CSZ) == sub;        // this lane's 4 accumulator couts do
     int t = q_major ? v - vq * P : vq;
     const int stripe = t & (GG_ACC_STRIPES - 1);       // GroupNorm accumulator stripe of this position tile
     const int t1 = mdiv(t, tiles_w, mg.tw);
@@ -274,6 +289,16 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         const int q0 = K3 ? (TU * wave) / NW : s0, q1 = K3 ? (TU * (wave + 1)) / NW : s1;
         int lkh = K3 ? mdiv(q0, nch, mnch) : 0, lc = q0 - lkh * nch, lidx = q0;   // load iterator
         bf16x8 wr[NTRIP][SPT][CT];
+        if constexpr (NS > 1) {
+            // an MFMA output row (cout) depends on its own weight row only: the rows of the other sub-workgroups are never loaded, their
+            // accumulator rows never stored (zeros once, so that no NaN pattern is ever fed to the matrix core)
+#pragma unroll
+            for (int r = 0; r < NTRIP; ++r)
+#pragma unroll
+                for (int u = 0; u < SPT; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) wr[r][u][ct] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
         auto load_w = [&](bf16x8 (&a)[SPT][CT]) {
             if constexpr (K3) {
                 const bf16_t *tile = wbase + (((long long)(lkh * 3) * p.nchunk + cbase + lc) << 10) + wl0;
@@ -281,7 +306,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        if constexpr (NS == 1) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);
+                        else if (wact) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);     // (foreign rows: stale registers)
+                    }
                 const int adv = (lidx + 1 < q1) ? 1 : 0;
                 lidx += adv;
                 lc += adv;
@@ -552,12 +580,23 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             const int q0 = (nch * wave) / NW, q1 = (nch * (wave + 1)) / NW;
             int lc = q0;
             bf16x8 ws[2][SPT1][CT];
+            if constexpr (NS > 1) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int u = 0; u < SPT1; ++u)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) ws[r][u][ct] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
             auto load_ws = [&](bf16x8 (&a)[SPT1][CT]) {
 #pragma unroll
                 for (int u = 0; u < SPT1; ++u) {
                     const bf16_t *tile = wsk + ((long long)(cbase + lc) << 10) + wl0;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        if constexpr (NS == 1) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                        else if (wact) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                    }
                     lc += (lc + 1 < q1) ? 1 : 0;
                 }
             };
@@ -608,7 +647,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         const int i = tid + 512 * kk;
         resv[kk] = u32x2{0u, 0u};
         const int oh = h0 + ((i >> 6) / CT) * RPT + (i & 15) / TWI;
-        if (p.residual && i < MT * CT * 64 && oh < p.Ho)
+        if (p.residual && i < MT * CT * 64 && oh < p.Ho && oact)
             resv[kk] = *reinterpret_cast<const u32x2 *>(p.residual + (((long long)n * p.Ho + oh) * p.Wo + (w0 + (i & 15) % TWI)) * p.Cout_pad + co_thr);
     }
     f32x4 *red = reinterpret_cast<f32x4 *>(box);
@@ -645,6 +684,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     for (int kk = 0; kk < EPI; ++kk) {
         const int i = tid + 512 * kk;
         if (i >= MT * CT * 64) break;
+        if (!oact) continue;                                // cout sub-split: another workgroup's couts
         f32x4 a = red[i];
 #pragma unroll
         for (int w = 1; w < NWR; ++w) a += red[w * MT * CT * 64 + i];
@@ -713,14 +753,15 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             for (int w = 0; w < NW; ++w)
                 if (w % CT == ct) t += statp[w][cw][which];  // waves whose slices carry cout tile ct, fixed order
             const long long fx = __double2ll_rn((double)t * (double)(which ? GG_ACC_SQ_SCALE : GG_ACC_SUM_SCALE));
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.gn_acc + ((((long long)n * GG_ACC_STRIPES + stripe) * p.Cout_pad + g * 32 + half * 16 + c) * 2 + which)),
-                      (unsigned long long)fx);
+            if (NS == 1 || cw / CSZ == sub)                  // cout sub-split: the sums of this workgroup's couts only
+                atomicAdd(reinterpret_cast<unsigned long long *>(p.gn_acc + ((((long long)n * GG_ACC_STRIPES + stripe) * p.Cout_pad + g * 32 + half * 16 + c) * 2 + which)),
+                          (unsigned long long)fx);
         }
     }
     GG_STAMP(7);
 }
 
-struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; int nstage_s, nch_stage_s; };
+struct BoxPlan { int TWI, MT, CT, nstage, nch_stage, gn_bytes, q_major; long long smem; int nstage_s, nch_stage_s, NS; };
 
 // Cost model: bytes one CU has to take in (its weight slice + its input box), times the number of rounds the grid needs on
 // 256 CUs.  Smallest wins; ties go to the larger tile (fewer redundant halo bytes overall).
@@ -740,7 +781,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     const int RPT = 16 / TWI;
     const long long wbytes16 = 16LL * (k3 ? 9 : 1) * p.nchunk * 32 * 2;   // weight slice of 16 output channels
     double best = 0;
-    int bMT = 0, bCT = 0;
+    int bMT = 0, bCT = 0, bNS = 1;
     // tile heights: powers of two, plus 12 / 6 / 3 rows for 16-wide tiles so that 240 (not 160 or 320) workgroups cover the
     // 64 / 32 / 16-row levels; the last row tile may be ragged (rows >= Ho are computed on zero padding and not stored)
     for (int MT : {12, 8, 6, 4, 3, 2, 1}) {
@@ -758,11 +799,19 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
             const long long cap_c = lds_cap / plane_c > 0 ? lds_cap / plane_c : 1;
             const long long nst = (p.nchunk + cap_c - 1) / cap_c;
             const double cost = (double)(wbytes16 * CT + boxb) * (double)((blocks + 255) / 256) * (1.0 + 0.15 * (double)(nst - 1));
-            if (!bMT || cost < best * 0.97) { best = cost; bMT = MT; bCT = CT; }
+            if (!bMT || cost < best * 0.97) { best = cost; bMT = MT; bCT = CT; bNS = 1; }
+            // cout sub-split (weight-bound 3x3 convs of the 8x8 / 4x4 levels; instantiated shapes only): NS workgroups per 16-cout tile,
+            // each taking in 1 / NS of its weight rows and the whole box
+            if (GG_BOX_COUT_SUBSPLIT && CT == 1 && k3 && !p.upsample && ((TWI == 4 && MT == 1) || (TWI == 8 && MT == 2)))
+                for (int NS : {2, 4}) {
+                    if (blocks * NS > 256) continue;                       // one round only
+                    const double cs = (double)(wbytes16 / NS + boxb) * (1.0 + 0.15 * (double)(nst - 1));
+                    if (cs < best * 0.97) { best = cs; bMT = MT; bCT = CT; bNS = NS; }
+                }
         }
     }
     if (!bMT) return false;                                          // filled grids: the halo / wide-tile kernels win
-    const int MT = bMT, CT = bCT, TH = MT * RPT;
+    const int MT = bMT, CT = bCT, NS = bNS, TH = MT * RPT;
     const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
     const long long plane = (long long)((rows + 15) / 16) * 1024;   // whole 16-row DMA blocks
     long long cap = lds_cap / plane;
@@ -789,11 +838,11 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
         nch_stage_s = (int)((nck + nstage_s - 1) / nstage_s);
         if (smem < nch_stage_s * plane1) smem = nch_stage_s * plane1;
     }
-    pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes, nstage_s, nch_stage_s};
+    pl = {TWI, MT, CT, nstage, nch_stage, gn_bytes, cost_q <= cost_p ? 1 : 0, smem + gn_bytes, nstage_s, nch_stage_s, NS};
     return true;
 }
 
-template <int TWI, int MT, int CT, int UP, int K3, int SK = 0>
+template <int TWI, int MT, int CT, int UP, int K3, int SK = 0, int NS = 1>
 static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream)
 {
     // the attribute is per device: one bit per device ordinal (setting it twice from two threads is harmless)
@@ -802,18 +851,18 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     if (hipGetDevice(&dev) != hipSuccess) return GG_ERR_HIP;
     const unsigned long long dev_bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_box2d_kernel<TWI, MT, CT, UP, K3, SK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_mask.fetch_or(dev_bit, std::memory_order_release);
     }
     const int tiles_h = (p.Ho + MT * (16 / TWI) - 1) / (MT * (16 / TWI)), tiles_w = p.Wo / TWI;
-    dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT))));
-    const int Pn = p.N * tiles_h * tiles_w, Qn = p.Cout_pad / (16 * CT);
+    dim3 grid((unsigned)(p.N * tiles_h * tiles_w * (p.Cout_pad / (16 * CT)) * NS));
+    const int Pn = p.N * tiles_h * tiles_w, Qn = p.Cout_pad / (16 * CT) * NS;      // (cout sub-split: NS workgroups per cout tile)
     const int nch_last = p.nchunk - (pl.nstage - 1) * pl.nch_stage;
     const int nck_s = (p.skip_C1 + p.skip_C2) / 32, nch_s_last = pl.nstage_s ? nck_s - (pl.nstage_s - 1) * pl.nch_stage_s : 0;
     const BoxMagic mg = {gg_magic(pl.q_major ? Pn : Qn), gg_magic(tiles_w), gg_magic(tiles_h), gg_magic(pl.nch_stage), gg_magic(nch_last), Qn,
                          gg_magic(pl.nch_stage_s), gg_magic(nch_s_last), pl.nstage_s, pl.nch_stage_s};
-    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3, SK>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
+    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3, SK, NS>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
                        pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x, mg);
     GG_CHECK_LAUNCH();
     return GG_OK;
@@ -830,9 +879,19 @@ static int dispatch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stre
         case 164: return launch_box<16, 4, CT, UP, K3, SK>(p, pl, stream);
         case 162: return launch_box<16, 2, CT, UP, K3, SK>(p, pl, stream);
         case 84: return launch_box<8, 4, CT, UP, K3, SK>(p, pl, stream);
-        case 82: return launch_box<8, 2, CT, UP, K3, SK>(p, pl, stream);
+        case 82:
+            if constexpr (CT == 1 && UP == 0 && K3 == 1) {
+                if (pl.NS == 2) return launch_box<8, 2, CT, UP, K3, SK, 2>(p, pl, stream);
+                if (pl.NS == 4) return launch_box<8, 2, CT, UP, K3, SK, 4>(p, pl, stream);
+            }
+            return pl.NS == 1 ? launch_box<8, 2, CT, UP, K3, SK>(p, pl, stream) : GG_ERR_UNSUPPORTED;
         case 81: return launch_box<8, 1, CT, UP, K3, SK>(p, pl, stream);
-        case 41: return launch_box<4, 1, CT, UP, K3, SK>(p, pl, stream);
+        case 41:
+            if constexpr (CT == 1 && UP == 0 && K3 == 1) {
+                if (pl.NS == 2) return launch_box<4, 1, CT, UP, K3, SK, 2>(p, pl, stream);
+                if (pl.NS == 4) return launch_box<4, 1, CT, UP, K3, SK, 4>(p, pl, stream);
+            }
+            return pl.NS == 1 ? launch_box<4, 1, CT, UP, K3, SK>(p, pl, stream) : GG_ERR_UNSUPPORTED;
         default: return GG_ERR_UNSUPPORTED;
     }
 }

@@ -228,6 +228,10 @@ BOX_CASES = [
     ("box_w4_n3", 3, 64, 32, (4, 4), False),
     ("box_w8_up", 2, 160, 160, (4, 4), True),
     ("box_w8_three_stages", 1, 1280, 64, (8, 8), False),
+    # cout sub-split (2 / 4 workgroups per 16-cout tile, each taking its own weight rows): padded couts, batch 2, 8x8 level
+    ("box_w4_sub4_cout40", 1, 800, 40, (4, 4), False),
+    ("box_w4_sub2_n2", 2, 320, 800, (4, 4), False),
+    ("box_w8_sub2_cout72", 1, 640, 72, (8, 8), False),
     # ragged row tiles (12 / 6 / 3 rows): 240 workgroups on the 64 / 32 / 16-row levels, last tile partly outside the image
     ("box_ragged12", 1, 160, 160, (64, 64), False),
     ("box_ragged6", 1, 64, 320, (32, 32), False),

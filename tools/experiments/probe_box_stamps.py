@@ -5,7 +5,7 @@ all waves done, combine visible, end -- relative to the first workgroup's entry.
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from jointimagegeneration_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", "libS.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", os.environ.get("GG_STAMP_LIB", "libS.so"))
 import ctypes as C
 import torch
 from jointimagegeneration_amd import ops
