@@ -38,6 +38,11 @@
 #endif
 #include <stdlib.h>
 
+// The compiler hoists loop-invariant address arithmetic of the conditional blocks inside the stage loop (accumulator fold, in-place
+// prologue, first-stage operand offsets: ~350 instructions, 0.7 us at batch 1) in front of the loop, i.e. in front of the box DMAs.
+// A value laundered through a volatile asm INSIDE a block pins everything computed from it to that block.
+__device__ __forceinline__ int gg_here(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14), as builtins so that the
 // compiler's own wait-count pass sees them
 #define GG_WAITCNT_IMM(VM) ((((VM) & 15) | (((VM) >> 4) << 14)) | 0x70)
@@ -69,6 +74,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     p.N = gg_pin(p_arg.N); p.H = gg_pin(p_arg.H); p.W = gg_pin(p_arg.W); p.C1 = gg_pin(p_arg.C1); p.C2 = gg_pin(p_arg.C2);
     p.nchunk1 = gg_pin(p_arg.nchunk1); p.nchunk = gg_pin(p_arg.nchunk); p.src1 = gg_pin(p_arg.src1); p.src2 = gg_pin(p_arg.src2);
     p.bias = gg_pin(p_arg.bias); p.bias_stride = gg_pin(p_arg.bias_stride); p.prologue_act = gg_pin(p_arg.prologue_act);
+    // ... and one field of every other 64-byte line of the kernarg segment (0xc0, 0x100, 0x140): a later scalar load of a line nobody
+    // has touched is a full memory round trip, and the compiler had five of them, serial, between kernel entry and the first DMA
+    p.Cout = gg_pin(p_arg.Cout); p.Cout_pad = gg_pin(p_arg.Cout_pad);
+    p.gn_acc = gg_pin(p_arg.gn_acc); p.pro_acc1 = gg_pin(p_arg.pro_acc1); p.pro_clog = gg_pin(p_arg.pro_clog); p.skip_C1 = gg_pin(p_arg.skip_C1);
     const int tiles_h = gg_pin(tiles_h_arg), tiles_w = gg_pin(tiles_w_arg), nstage = gg_pin(nstage_arg), nch_stage = gg_pin(nch_stage_arg),
               gn_bytes = gg_pin(gn_bytes_arg), q_major = gg_pin(q_major_arg), nblocks = gg_pin(nblocks_arg);
     BoxMagic mg;
@@ -169,9 +178,10 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     long long psum = 0;                                // 8 lanes per (group, sum | sumsq) task
     __shared__ float pro_gmean[32], pro_grstd[32];
     if (acc_mode) {
+        const int tidh = gg_here(tid);
 #pragma unroll
         for (int k = 0; k < ACPT; ++k) {
-            const int c = tid + 512 * k;
+            const int c = tidh + 512 * k;
             pgam[k] = 0.f;
             pbet[k] = 0.f;
             if (c < p.pro_clog) {
@@ -266,16 +276,18 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
 #pragma unroll
                 for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             wbase = p.weight + ((long long)g * NTAPS * p.nchunk << 10) + half * 512;
-            wl0 = fr * 32 + swz64(fr, fq) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
+            const int laneh = gg_here(lane), frh = laneh & 15, fqh = laneh >> 4;      // (not hoisted in front of the DMAs)
+            wl0 = frh * 32 + swz64(frh, fqh) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
             // per-lane part of the activation-operand address for the three kw taps (1x1: one)
             if constexpr (LINE_SWZ) {
+                const int pos_rh = frh / TWI, pos_ch = frh % TWI;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int rwk = UP ? ((pos_c + k + 1) >> 1) : (pos_c + k);
-                    lane_off[k] = (UP ? 0 : pos_r * (HW * 64)) + rwk * 64 + ((fq ^ bsw(0, rwk)) * 16);
+                    const int rwk = UP ? ((pos_ch + k + 1) >> 1) : (pos_ch + k);
+                    lane_off[k] = (UP ? 0 : pos_rh * (HW * 64)) + rwk * 64 + ((fqh ^ bsw(0, rwk)) * 16);
                 }
             } else if constexpr (!K3) {
-                lane_off[0] = fr * 64 + ((fq ^ ((fr >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
+                lane_off[0] = frh * 64 + ((fqh ^ ((frh >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
             }
         }
         // ---- weight stream of this wave.  3x3: the wave owns units q in [q0, q1) of the (kh, chunk) grid, a unit = the three kw taps
@@ -335,7 +347,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             // 64 tasks (32 groups x {sum, sumsq}), 8 lanes each: lane `part` reads channels part, part + 8, ... of the group's cpg <= 64
             // per-channel fixed-point sums straight from L2 -- at most 8 loads per lane, ALL in flight at once, while the box is landing
             // (no LDS atomics, no staging area; integer adds are exact in any order)
-            const int task = tid >> 3, part = tid & 7, gg = task >> 1, which = task & 1;
+            const int tidh = gg_here(tid);
+            const int task = tidh >> 3, part = tidh & 7, gg = task >> 1, which = task & 1;
             const int cpg = p.pro_clog >> 5;
             long long v[8];
 #pragma unroll
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
 
         if (acc_mode && st == 0) {
             // groups -> mean / rstd (fp64; the sum | sumsq lanes of a group are neighbours), channels -> scale / shift rows of ALL chunks
+            const int tidh = gg_here(tid);
             const int cpg = p.pro_clog >> 5;
             const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
             {
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                 psum += __shfl_xor(psum, 2);
                 psum += __shfl_xor(psum, 4);                   // the 8 parts of a task
                 const long long other = __shfl_xor(psum, 8);   // sumsq task of the same group sits 8 lanes up
-                if ((tid & 15) == 0) {
+                if ((tidh & 15) == 0) {
                     const double a = (double)psum * (1.0 / (double)GG_ACC_SUM_SCALE);
                     const double b = (double)other * (1.0 / (double)GG_ACC_SQ_SCALE);
                     const double cnt = (double)p.H * (double)p.W * (double)cpg;
@@ -381,15 +395,15 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                     const double mean = a * inv;
                     double var = b * inv - mean * mean;
                     if (var < 0.0) var = 0.0;
-                    pro_gmean[tid >> 4] = (float)mean;
-                    pro_grstd[tid >> 4] = rsqrtf((float)var + p.pro_eps);
+                    pro_gmean[tidh >> 4] = (float)mean;
+                    pro_grstd[tidh >> 4] = rsqrtf((float)var + p.pro_eps);
                 }
             }
             GG_BOX_LDS_BARRIER();
             const int Ct = p.nchunk * 32;
 #pragma unroll
             for (int k = 0; k < ACPT; ++k) {
-                const int c = tid + 512 * k;
+                const int c = tidh + 512 * k;
                 if (c < Ct) {
                     float sc = 0.f, sh = 0.f;
                     if (c < p.pro_clog) {
@@ -404,6 +418,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             GG_BOX_LDS_BARRIER();
         }
         if (p.prologue_act) {     // GroupNorm affine (* SiLU) in place, once per staged element; padding stays zero
+            const int laneh = gg_here(lane), lrowh = laneh >> 2, lsloth = laneh & 3;
             // rows of the table: external tables hold this stage's chunks only, the accumulator fold holds all chunks of the conv
             const float *gsc = gns + (acc_mode ? cbase * 32 : 0);
             const int gsh = (acc_mode ? p.nchunk : nch) * 32;
@@ -424,30 +439,30 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             if constexpr (!K3) {
                 // 1x1 boxes (row-based swizzle): the lane's 8 channels of a chunk are the same in every 16-row block, so its scale / shift
                 // rows are read once per chunk, not once per piece
-                const int q = lslot ^ bsw(lrow, 0);
+                const int q = lsloth ^ bsw(lrowh, 0);
                 for (int c = wave; c < nch; c += NW) {
                     const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
                     const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sc), sc1 = *reinterpret_cast<const f32x4 *>(sc + 4);
                     const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sh), sh1 = *reinterpret_cast<const f32x4 *>(sh + 4);
 #pragma unroll 2
                     for (int rbk = 0; rbk < NRB; ++rbk) {
-                        const int row = rbk * 16 + lrow;
+                        const int row = rbk * 16 + lrowh;
                         const int hh = row / HW, hw = row - hh * HW;
                         const int ih = ih0 + hh, iw = iw0 + hw;
-                        if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xform(box + c * PLANE + rbk * 1024 + lane * 16, sc0, sc1, sh0, sh1);
+                        if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xform(box + c * PLANE + rbk * 1024 + laneh * 16, sc0, sc1, sh0, sh1);
                     }
                 }
             } else {
 #pragma unroll 2
                 for (int unit = wave; unit < nunit; unit += NW) {
                     const int c = unit / NRB, rbk = unit - c * NRB;
-                    const int row = rbk * 16 + lrow;
+                    const int row = rbk * 16 + lrowh;
                     const int hh = row / HW, hw = row - hh * HW;
                     const int ih = ih0 + hh, iw = iw0 + hw;
                     if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                        const int q = lslot ^ bsw(row, hw);
+                        const int q = lsloth ^ bsw(row, hw);
                         const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
-                        xform(box + c * PLANE + rbk * 1024 + lane * 16, *reinterpret_cast<const f32x4 *>(sc), *reinterpret_cast<const f32x4 *>(sc + 4),
+                        xform(box + c * PLANE + rbk * 1024 + laneh * 16, *reinterpret_cast<const f32x4 *>(sc), *reinterpret_cast<const f32x4 *>(sc + 4),
                               *reinterpret_cast<const f32x4 *>(sh), *reinterpret_cast<const f32x4 *>(sh + 4));
                     }
                 }

@@ -412,6 +412,14 @@ extern "C" int gg_groupnorm_apply(const void *src1, int32_t C1, const void *src2
 // producing convs (gg_conv_desc.gn_acc): no statistics launch at all.  Every block folds (sum, sumsq) of its sample's
 // channels into the scale/shift table in LDS (fp64 per group), then applies its share of the rows.  All global reads
 // (accumulators, gamma/beta, the thread's first pieces) are issued up front: one memory round trip per block.
+// Diagnostic build only (-DGG_GN_STAMPS, tools/experiments/probe_gn_stamps.py): s_memrealtime phase stamps of thread 0 of every block
+#ifdef GG_GN_STAMPS
+__device__ unsigned long long gg_gn_stamp_buf[4096 * 8];
+extern "C" int gg_gn_stamps_read(unsigned long long *host, int n) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(gg_gn_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 1; }
+#define GG_GSTAMP(K) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) gg_gn_stamp_buf[blockIdx.x * 8 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GG_GSTAMP(K) do { } while (0)
+#endif
 #define GG_ACC_SUM_SCALE_D 268435456.0   /* 2^28, must match gg_conv.h */
 #define GG_ACC_SQ_SCALE_D 1048576.0      /* 2^20 */
 __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restrict__ s1, int C1, const long long *__restrict__ acc1,
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     s1 = gg_pin(s1); C1 = gg_pin(C1); acc1 = gg_pin(acc1); s2 = gg_pin(s2); C2 = gg_pin(C2); acc2 = gg_pin(acc2); S = gg_pin(S);
     C_logical = gg_pin(C_logical); gamma = gg_pin(gamma); beta = gg_pin(beta); eps = gg_pin(eps); act = gg_pin(act); out = gg_pin(out);
     pmagic = gg_pin(pmagic);
+    GG_GSTAMP(0);
     const int C = C1 + C2;
     const int P = C >> 3;
     const int tid = threadIdx.x, n = blockIdx.y;
@@ -474,17 +483,20 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
             bet[k] = beta[c];
         }
     }
+    GG_GSTAMP(1);
     __syncthreads();                                   // gacc zeroed
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
         if (c < C_logical) {
             const int g = gg_div_small(c, rcpg);
+            if (k == 0) GG_GSTAMP(2);
             atomicAdd(&gacc[g][0], (unsigned long long)sa[k]);
             atomicAdd(&gacc[g][1], (unsigned long long)sb[k]);
         }
     }
     __syncthreads();
+    GG_GSTAMP(3);
     if (tid < 32) {
         const double a = (double)(long long)gacc[tid][0] * (1.0 / GG_ACC_SUM_SCALE_D);
         const double b = (double)(long long)gacc[tid][1] * (1.0 / GG_ACC_SQ_SCALE_D);
@@ -496,6 +508,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         grstd[tid] = rsqrtf((float)var + eps);
     }
     __syncthreads();
+    GG_GSTAMP(4);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int c = tid + 256 * k;
@@ -511,6 +524,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         }
     }
     __syncthreads();
+    GG_GSTAMP(5);
     auto emit = [&](long long i, const u32x4 raw) {
         const long long row = gg_fastdiv(i, P, pmagic);
         const int c0 = (int)(i - row * P) * 8;
@@ -536,6 +550,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
         const int c0 = (int)(i - row * P) * 8;
         emit(i, *reinterpret_cast<const u32x4 *>((c0 >= C1) ? b2 + row * C2 + (c0 - C1) : b1 + row * C1 + c0));
     }
+    GG_GSTAMP(6);
 }
 
 extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2,
