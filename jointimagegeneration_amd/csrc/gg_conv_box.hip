@@ -155,9 +155,8 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
 
     // final pass: thread -> f32x4 slot (tid & 63) of slices (tid >> 6) + 8k; with CT | 8 its 4 couts are the same for every k,
     // so the bias is fetched here, a whole kernel ahead of its use
-    const int co_thr = g * 32 + half * 16 + ((tid >> 6) % CT) * 16 + (lane >> 4) * 4;
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + (long long)n * p.bias_stride + co_thr);
+    int co_thr = 0;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};           // (requested right after the first stage's DMAs have been issued)
 
     // accumulators, weight base and operand lane offsets are set up AFTER the first stage's DMAs have been issued (a wave issues its
     // instructions one by one: whatever precedes the DMAs delays the landing of the box)
@@ -271,11 +270,17 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         }
         GG_STAMP(1);
         if (st == 0) {
+            const int gh = gg_pin(g), halfh = gg_pin(half), nh = gg_pin(n);      // (pinned: what follows stays behind the DMA issue)
+            {
+                const int tidh = gg_here(tid);
+                co_thr = gh * 32 + halfh * 16 + ((tidh >> 6) % CT) * 16 + ((tidh & 63) >> 4) * 4;
+                if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + (long long)nh * p.bias_stride + co_thr);
+            }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < CT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            wbase = p.weight + ((long long)g * NTAPS * p.nchunk << 10) + half * 512;
+            wbase = p.weight + ((long long)gh * NTAPS * p.nchunk << 10) + halfh * 512;
             const int laneh = gg_here(lane), frh = laneh & 15, fqh = laneh >> 4;      // (not hoisted in front of the DMAs)
             wl0 = frh * 32 + swz64(frh, fqh) * 8;      // pre-swizzled packed rows: cout row fr (and 16 + fr at +512 elements)
             // per-lane part of the activation-operand address for the three kw taps (1x1: one)
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         if (acc_mode && st == 0) {
             // groups -> mean / rstd (fp64; the sum | sumsq lanes of a group are neighbours), channels -> scale / shift rows of ALL chunks
             const int tidh = gg_here(tid);
-            const int cpg = p.pro_clog >> 5;
+            const int cpg = gg_pin(p.pro_clog) >> 5;              // (pinned here: the fp64 reciprocal below is not hoisted in front of the DMAs)
             const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
             {
                 psum += __shfl_xor(psum, 1);

@@ -420,6 +420,9 @@ extern "C" int gg_gn_stamps_read(unsigned long long *host, int n) { return hipMe
 #else
 #define GG_GSTAMP(K) do { } while (0)
 #endif
+#ifndef GG_GN_APPLY_ACC_LEAN
+#define GG_GN_APPLY_ACC_LEAN 1           /* one-piece-per-thread form of gn_apply_acc for batch-1 shapes (A/B: tools/experiments) */
+#endif
 #define GG_ACC_SUM_SCALE_D 268435456.0   /* 2^28, must match gg_conv.h */
 #define GG_ACC_SQ_SCALE_D 1048576.0      /* 2^20 */
 __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restrict__ s1, int C1, const long long *__restrict__ acc1,
@@ -553,6 +556,89 @@ __global__ __launch_bounds__(256) void gn_apply_acc_kernel(const bf16_t *__restr
     GG_GSTAMP(6);
 }
 
+// Batch-1 latent-UNet form of the above (one 16-byte piece per thread, < 2^31 elements, one sample per grid row): at ~2 ns per wave
+// instruction the kernel above spends 0.6 us before its first load (64-bit piece arithmetic) and ~1.5 us in its fold (LDS integer
+// atomics, four barriers, a scale / shift table for all channels).  Here: 32-bit piece arithmetic; the thread's piece, the (sum, sumsq)
+// of its fold channels and gamma / beta of ITS 8 channels all requested up front; per-channel sums parked in LDS (one barrier), 32
+// threads add their group's cpg entries (integers: exact, any order) and derive mean / rstd with the same formulas (second barrier);
+// every thread then forms the scale / shift of its own 8 channels from its groups' statistics -- no table, no third barrier.
+// Results are bit-identical to gn_apply_acc_kernel (same integer sums, same fp64 / fp32 expressions).
+template <int CPT>      // fold channels per thread: C <= 256 * CPT
+__global__ __launch_bounds__(256) void gn_apply_acc_lean_kernel(const bf16_t *__restrict__ s1, int C1, const long long *__restrict__ acc1,
+                                                                const bf16_t *__restrict__ s2, int C2, const long long *__restrict__ acc2,
+                                                                int S, int C_logical, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float eps, int act, bf16_t *__restrict__ out, unsigned pmagic)
+{
+    s1 = gg_pin(s1); C1 = gg_pin(C1); acc1 = gg_pin(acc1); s2 = gg_pin(s2); C2 = gg_pin(C2); acc2 = gg_pin(acc2); S = gg_pin(S);
+    C_logical = gg_pin(C_logical); gamma = gg_pin(gamma); beta = gg_pin(beta); pmagic = gg_pin(pmagic);
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+    const int C = C1 + C2, P = C >> 3;
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int pieces = S * P;
+    extern __shared__ __attribute__((aligned(16))) char lean_smem[];
+    i64x2 *csum = reinterpret_cast<i64x2 *>(lean_smem);          // [C_logical] (sum, sumsq), fixed point
+    __shared__ float gmean[32], grstd[32];
+    // the thread's piece and the affine of its 8 channels
+    const int i = blockIdx.x * 256 + tid;
+    const bool live = i < pieces;
+    const int row = live ? (int)__umulhi((unsigned)i, pmagic) : 0;            // i / P (pmagic != 0: host gate)
+    const int c0 = live ? (i - row * P) * 8 : 0;
+    const bool logical = live && c0 < C_logical;                                // (C_logical % 32 == 0: a piece is all logical or all padding)
+    const unsigned e1 = (unsigned)n * (unsigned)S * (unsigned)C1, e2 = (unsigned)n * (unsigned)S * (unsigned)C2;   // < 2^31 elements (host gate)
+    u32x4 pv = u32x4{0u, 0u, 0u, 0u};
+    if (live) pv = *reinterpret_cast<const u32x4 *>((c0 >= C1) ? s2 + e2 + (unsigned)row * (unsigned)C2 + (unsigned)(c0 - C1) : s1 + e1 + (unsigned)row * (unsigned)C1 + (unsigned)c0);
+    f32x4 g0 = f32x4{0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
+    if (logical) {
+        g0 = *reinterpret_cast<const f32x4 *>(gamma + c0); g1 = *reinterpret_cast<const f32x4 *>(gamma + c0 + 4);
+        b0 = *reinterpret_cast<const f32x4 *>(beta + c0); b1 = *reinterpret_cast<const f32x4 *>(beta + c0 + 4);
+    }
+    // fold channels tid + 256k: (sum, sumsq) over the stripes, parked in LDS
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C_logical) {
+            const long long *q = (c < C1) ? acc1 + ((long long)n * GG_ACC_STRIPES * C1 + c) * 2 : acc2 + ((long long)n * GG_ACC_STRIPES * C2 + (c - C1)) * 2;
+            const long long cs = (c < C1) ? (long long)C1 * 2 : (long long)C2 * 2;
+            i64x2 a = *reinterpret_cast<const i64x2 *>(q);
+#pragma unroll
+            for (int st = 1; st < GG_ACC_STRIPES; ++st) a += *reinterpret_cast<const i64x2 *>(q + st * cs);
+            csum[c] = a;
+        }
+    }
+    const int cpg = C_logical >> 5;
+    __syncthreads();
+    if (tid < 32) {
+        i64x2 t = i64x2{0, 0};
+        for (int j = 0; j < cpg; ++j) t += csum[tid * cpg + j];
+        const double a = (double)t[0] * (1.0 / GG_ACC_SUM_SCALE_D);
+        const double b = (double)t[1] * (1.0 / GG_ACC_SQ_SCALE_D);
+        const double cnt = (double)S * (double)cpg; double inv = (double)(1.0f / (float)cnt); inv = inv * (2.0 - cnt * inv);      // (as gn_apply_acc_kernel)
+        const double mean = a * inv;
+        double var = b * inv - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmean[tid] = (float)mean;
+        grstd[tid] = rsqrtf((float)var + eps);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
+    const bf16x8 v = __builtin_bit_cast(bf16x8, pv);
+    bf16x8 y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float sc = 0.f, sh = 0.f;
+        if (logical) {
+            const int g = gg_div_small(c0 + j, rcpg);
+            sc = grstd[g] * (j < 4 ? g0[j & 3] : g1[j & 3]);
+            sh = (j < 4 ? b0[j & 3] : b1[j & 3]) - gmean[g] * sc;
+        }
+        float t = (float)v[j] * sc + sh;
+        if (act) t = gg_silu(t);
+        y[j] = (bf16_t)t;
+    }
+    *reinterpret_cast<bf16x8 *>(out + ((unsigned)n * (unsigned)S + (unsigned)row) * (unsigned)C + (unsigned)c0) = y;
+}
+
 extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2,
                                       const int64_t *acc2, int32_t N, int64_t S, int32_t C_logical, const float *gamma,
                                       const float *beta, float eps, int32_t act, void *out, void *stream_)
@@ -568,6 +654,17 @@ extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_
     long long blocks = (pieces + 255) / 256;   // one piece per thread (256 / 512 / 1024 pieces per block: 1477 / 1496 / 1545 us per latent-UNet forward: the parallelism is worth more than the per-block fold)
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
+    // batch-1 latent-UNet shapes: one piece per thread, 32-bit element offsets, multiply-high piece decode
+    const unsigned pm = gg_magic_u32(pieces, C / 8);
+    if (GG_GN_APPLY_ACC_LEAN && blocks * 256 >= pieces && (long long)N * S * C < (1LL << 31) && (pm != 0 || C == 8) && C / 8 > 1) {
+        const size_t lds = (size_t)C_logical * 16;
+#define GG_LEAN(CPT) hipLaunchKernelGGL(gn_apply_acc_lean_kernel<CPT>, dim3((unsigned)blocks, N), dim3(256), lds, stream, (const bf16_t *)src1, C1, \
+                       (const long long *)acc1, (const bf16_t *)src2, C2, (const long long *)acc2, (int)S, C_logical, gamma, beta, eps, act, (bf16_t *)out, pm)
+        if (C_logical <= 256) GG_LEAN(1); else if (C_logical <= 512) GG_LEAN(2); else if (C_logical <= 1024) GG_LEAN(4); else GG_LEAN(8);
+#undef GG_LEAN
+        GG_CHECK_LAUNCH();
+        return GG_OK;
+    }
     hipLaunchKernelGGL(gn_apply_acc_kernel, dim3((unsigned)blocks, N), dim3(256), C * 2 * sizeof(float), stream, (const bf16_t *)src1, C1,
                        (const long long *)acc1, (const bf16_t *)src2, C2, (const long long *)acc2, (long long)S, C_logical, gamma, beta, eps,
                        act, (bf16_t *)out, gg_magic_u32(pieces, C / 8));
