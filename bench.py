@@ -301,13 +301,14 @@ def batch8_sample(pipe, args):
     pipe.run_volume(N=N, mask_size=size, depth=args.slices, hw=512, seed=11, ccdm_init_t=10005, max_slices=3)     # repack / capture at N = 8
     t10, _ = ccdm(10)
     t20, lab = ccdm(20)
+    t10, t20 = min(t10, ccdm(10)[0]), min(t20, ccdm(20)[0])          # (the first pair carries allocator / capture noise: 115-168 ms per step run to run)
     s4 = ldm(lab, 4)
     s8 = ldm(lab, 8)
     step_s, slice_s = (t20 - t10) / 10.0, (s8 - s4) / 4.0
     per_batch = args.ccdm_steps * step_s + args.slices * slice_s
     return {"value": round(N * VOXELS_PER_VOLUME / per_batch, 1), "unit": "voxels/s", "headline": False, "extrapolated": True,
             "ccdm_step_ms_n8": round(step_s * 1e3, 2), "ldm_slice_ms_n8": round(slice_s * 1e3, 2), "seconds_per_8_volumes": round(per_batch, 1),
-            "sample": "N=8 batch: (20-step - 10-step CCDM chain)/10, (8-slice - 4-slice loop)/4, x250 steps + x256 slices"}
+            "sample": "N=8 batch: (20-step - 10-step CCDM chain, best of two each)/10, (8-slice - 4-slice loop)/4, x250 steps + x256 slices"}
 
 
 # ------------------------------------------------------------------------------------------------ rank body
