@@ -33,6 +33,9 @@
 #ifndef GG_BOX_ACC_SILU_MAX_ELEMS
 #define GG_BOX_ACC_SILU_MAX_ELEMS 0          /* elements of a workgroup's box up to which a SiLU norm is folded into the conv (0: never; A/B: tools/experiments) */
 #endif
+#ifndef GG_BOX_NW
+#define GG_BOX_NW 8                          /* waves per workgroup (8: two per SIMD; 4: one per SIMD -- A/B: tools/experiments) */
+#endif
 #ifndef GG_BOX_COUT_SUBSPLIT
 #define GG_BOX_COUT_SUBSPLIT 1               /* 3x3 convs of the 8x8 / 4x4 levels: 2 or 4 workgroups per 16-cout tile (A/B: tools/experiments) */
 #endif
@@ -52,7 +55,7 @@ __device__ __forceinline__ int gg_here(int v) { asm volatile("" : "+v"(v)); retu
 // Diagnostic build only (tools/experiments/README.md): -DGG_BOX_STAMPS records s_memrealtime (100 MHz) phase stamps of waves 0 and 7
 // of every workgroup into gg_conv_desc.workspace when path_hint == 98.
 #ifdef GG_BOX_STAMPS
-#define GG_STAMP(K) do { if (p.path_hint == 98 && p.ws && lane == 0 && (wave == 0 || wave == 7)) \
+#define GG_STAMP(K) do { if (p.path_hint == 98 && p.ws && lane == 0 && (wave == 0 || wave == GG_BOX_NW - 1)) \
     reinterpret_cast<unsigned long long *>(p.ws)[(blockIdx.x * 2 + (wave ? 1 : 0)) * 16 + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GG_STAMP(K) do { } while (0)
@@ -66,7 +69,7 @@ __device__ __forceinline__ int gg_mdiv(int n, unsigned magic) { return (int)__um
 static unsigned gg_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }   // d == 1: handled by the caller
 
 template <int TWI, int MT, int CT, int UP, int K3, int SK = 0, int NS = 1>
-__global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg, const int tiles_h_arg, const int tiles_w_arg, const int nstage_arg,
+__global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvParams p_arg, const int tiles_h_arg, const int tiles_w_arg, const int nstage_arg,
                                                          const int nch_stage_arg, const int gn_bytes_arg, const int q_major_arg, const int nblocks_arg, const BoxMagic mg_arg)
 {
     // the arguments the block decode and the first DMAs need, in ONE scalar-load batch (gg_pin); the rest load lazily
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     mg.nch_last = gg_pin(mg_arg.nch_last); mg.Q = gg_pin(mg_arg.Q);
     mg.nch_s = mg_arg.nch_s; mg.nch_s_last = mg_arg.nch_s_last; mg.nstage_s = mg_arg.nstage_s; mg.nch_stage_s = mg_arg.nch_stage_s;
     // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
-    constexpr int TW = TWI, NW = 8;
+    constexpr int TW = TWI, NW = GG_BOX_NW, NTH = NW * 64;
     constexpr int RPT = 16 / TWI;
     constexpr int TH = MT * RPT;                      // output rows of the workgroup
     // Weight trips (4 k-steps each) kept in flight per wave: measured on the latent-UNet forward (same box, hipGraph replay):
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // Cout sub-split: a weight load instruction moves 1 / NS of the bytes, so the ring is NS times deeper for the same bytes in flight
     // (phase stamps of the 800 -> 800 conv at 4x4: 50 workgroups x 230 KB and 200 x 58 KB both take ~8 us entry to end -- 1.7 us to
     // the first DMA, ~2.8 us until the box has landed, ~2 us of k-loop, 1.2 us of combine and epilogue; the split buys ~0.5 us).
-    constexpr int NTRIP = 2 * NS;   // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
+    constexpr int NTRIP = 2 * NS * (8 / NW);   // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
     constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
     constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // (sum, sumsq) the producing convs left, gamma and beta, requested ahead of the box DMAs (vmcnt counts in order: they have
     // landed when the box has); folded into the scale / shift table of ALL input channels once the first box is in LDS.
     const bool acc_mode = p.prologue_act && p.pro_acc1 != nullptr;
-    constexpr int ACPT = 4;                            // channels per thread: C1 + C2 <= 2048 (host gate)
+    constexpr int ACPT = 2048 / NTH;                   // channels per thread: C1 + C2 <= 2048 (host gate)
     float pgam[ACPT], pbet[ACPT];
     long long psum = 0;                                // 8 lanes per (group, sum | sumsq) task
     __shared__ float pro_gmean[32], pro_grstd[32];
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
         const int tidh = gg_here(tid);
 #pragma unroll
         for (int k = 0; k < ACPT; ++k) {
-            const int c = tidh + 512 * k;
+            const int c = tidh + NTH * k;
             pgam[k] = 0.f;
             pbet[k] = 0.f;
             if (c < p.pro_clog) {
@@ -353,12 +356,13 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             // per-channel fixed-point sums straight from L2 -- at most 8 loads per lane, ALL in flight at once, while the box is landing
             // (no LDS atomics, no staging area; integer adds are exact in any order)
             const int tidh = gg_here(tid);
-            const int task = tidh >> 3, part = tidh & 7, gg = task >> 1, which = task & 1;
+            constexpr int LPT = NTH / 64;                     // lanes per task (8 waves: 8, 4 waves: 4)
+            const int task = tidh / LPT, part = tidh % LPT, gg = task >> 1, which = task & 1;
             const int cpg = p.pro_clog >> 5;
-            long long v[8];
+            long long v[64 / LPT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = part + 8 * i, c = gg * cpg + j;
+            for (int i = 0; i < 64 / LPT; ++i) {
+                const int j = part + LPT * i, c = gg * cpg + j;
                 v[i] = 0;
                 if (j < cpg) {
                     const long long *q = (c < p.C1) ? p.pro_acc1 + ((long long)n * p.C1 + c) * 2 : p.pro_acc2 + ((long long)n * p.C2 + (c - p.C1)) * 2;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) psum += v[i];
+            for (int i = 0; i < 64 / LPT; ++i) psum += v[i];
         }
         // this wave's DMAs have landed once only its NTRIP*SPT*CT weight loads are outstanding; then zero ITS padding slots; then barrier
         __builtin_amdgcn_s_waitcnt(GG_WAITCNT_IMM(NTRIP * SPT * CT));
@@ -387,11 +391,12 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
             const int cpg = gg_pin(p.pro_clog) >> 5;              // (pinned here: the fp64 reciprocal below is not hoisted in front of the DMAs)
             const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
             {
+                constexpr int LPT = NTH / 64;
                 psum += __shfl_xor(psum, 1);
                 psum += __shfl_xor(psum, 2);
-                psum += __shfl_xor(psum, 4);                   // the 8 parts of a task
-                const long long other = __shfl_xor(psum, 8);   // sumsq task of the same group sits 8 lanes up
-                if ((tidh & 15) == 0) {
+                if constexpr (LPT == 8) psum += __shfl_xor(psum, 4);      // the LPT parts of a task
+                const long long other = __shfl_xor(psum, LPT);            // sumsq task of the same group sits LPT lanes up
+                if ((tidh & (2 * LPT - 1)) == 0) {
                     const double a = (double)psum * (1.0 / (double)GG_ACC_SUM_SCALE);
                     const double b = (double)other * (1.0 / (double)GG_ACC_SQ_SCALE);
                     const double cnt = (double)p.H * (double)p.W * (double)cpg;
@@ -400,15 +405,15 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
                     const double mean = a * inv;
                     double var = b * inv - mean * mean;
                     if (var < 0.0) var = 0.0;
-                    pro_gmean[tidh >> 4] = (float)mean;
-                    pro_grstd[tidh >> 4] = rsqrtf((float)var + p.pro_eps);
+                    pro_gmean[tidh / (2 * LPT)] = (float)mean;
+                    pro_grstd[tidh / (2 * LPT)] = rsqrtf((float)var + p.pro_eps);
                 }
             }
             GG_BOX_LDS_BARRIER();
             const int Ct = p.nchunk * 32;
 #pragma unroll
             for (int k = 0; k < ACPT; ++k) {
-                const int c = tidh + 512 * k;
+                const int c = tidh + NTH * k;
                 if (c < Ct) {
                     float sc = 0.f, sh = 0.f;
                     if (c < p.pro_clog) {
@@ -659,12 +664,12 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     // ---- combine the 8 waves (fixed order), then bias / residual / store.  red[wave][tt][ct][lane] is lane-contiguous:
     //      conflict-free 1 KiB wave writes and reads.
     // the thread's residual values of the final pass are requested now, a barrier and the 8-wave combine ahead of their use
-    constexpr int EPI = (MT * CT * 64 + 511) / 512;
+    constexpr int EPI = (MT * CT * 64 + NTH - 1) / NTH;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     u32x2 resv[EPI];
 #pragma unroll
     for (int kk = 0; kk < EPI; ++kk) {
-        const int i = tid + 512 * kk;
+        const int i = tid + NTH * kk;
         resv[kk] = u32x2{0u, 0u};
         const int oh = h0 + ((i >> 6) / CT) * RPT + (i & 15) / TWI;
         if (p.residual && i < MT * CT * 64 && oh < p.Ho && oact)
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     f32x4 *red = reinterpret_cast<f32x4 *>(box);
     // MT * CT > 16 (12 position tiles x 2 cout tiles: the 320 -> 320 upsample conv to 64x64 on 240 instead of 480 workgroups): eight slabs
     // would not fit the LDS, so waves 4-7 ADD their accumulators into the slabs of waves 0-3 in a second phase (fixed order)
-    constexpr bool TWO_PHASE = MT * CT > 16;
+    constexpr bool TWO_PHASE = NW == 8 && MT * CT > 16;
     constexpr int NWR = TWO_PHASE ? 4 : NW;
     if constexpr (!TWO_PHASE) {
 #pragma unroll
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < EPI; ++kk) {
-        const int i = tid + 512 * kk;
+        const int i = tid + NTH * kk;
         if (i >= MT * CT * 64) break;
         if (!oact) continue;                                // cout sub-split: another workgroup's couts
         f32x4 a = red[i];
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(512) void conv_box2d_kernel(const ConvParams p_arg,
     if (stats) {
         // a thread's slices (tid>>6) + 8k share their 4 couts; its lane's position (l & 15) is reduced over the 16 lanes of the row
         // by DPP moves, the 8 waves through LDS in a fixed order, then ONE wave instruction of 64-bit integer atomics per block
-        __shared__ float statp[8][16][2];                    // [wave][cq * 4 + j][sum | sumsq]
+        __shared__ float statp[NW][16][2];                    // [wave][cq * 4 + j][sum | sumsq]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float a = gg_row16_sum(ssum[j]), b = gg_row16_sum(ssq[j]);
@@ -813,7 +818,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             const long long blocks = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
-            if (blocks > max_blocks || (MT * CT > 16 ? 4LL : 8LL) * MT * CT * 1024 > lds_cap) continue;      // grid cap; the combine area (8 slabs, or 4 in two phases) must fit
+            if (blocks > max_blocks || (GG_BOX_NW == 8 && MT * CT > 16 ? 4LL : (long long)(GG_BOX_NW < 8 ? GG_BOX_NW : 8)) * MT * CT * 1024 > lds_cap) continue;      // grid cap; the combine area (8 slabs, or 4 in two phases) must fit
             // every extra LDS stage is another exposed staging round trip
             const long long plane_c = (long long)((rows + 15) / 16) * 1024;
             const long long cap_c = lds_cap / plane_c > 0 ? lds_cap / plane_c : 1;
@@ -840,7 +845,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     if (TWI == 4 && nstage > 1) return false;                        // 4x4 levels with > 1 stage: the split-K tiny kernel fills more CUs
     const int nch_stage = (p.nchunk + nstage - 1) / nstage;
     long long smem = nch_stage * plane;
-    const long long red = (MT * CT > 16 ? 4LL : 8LL) * MT * CT * 64 * 16;      // [wave][tt][ct][lane] f32x4 (two-phase combine above 16 tiles)
+    const long long red = (GG_BOX_NW == 8 && MT * CT > 16 ? 4LL : (long long)GG_BOX_NW) * MT * CT * 64 * 16;      // [wave][tt][ct][lane] f32x4 (two-phase combine above 16 tiles)
     if (smem < red) smem = red;
     // scale / shift rows in front of the box: external tables are DMA'd per stage, the accumulator fold keeps all chunks of the conv
     const int gn_bytes = p.prologue_act ? ((p.pro_acc1 ? p.nchunk : nch_stage) * 32 * 8 + 1023) / 1024 * 1024 : 0;
@@ -882,7 +887,7 @@ static int launch_box(const ConvParams &p, const BoxPlan &pl, hipStream_t stream
     const int nck_s = (p.skip_C1 + p.skip_C2) / 32, nch_s_last = pl.nstage_s ? nck_s - (pl.nstage_s - 1) * pl.nch_stage_s : 0;
     const BoxMagic mg = {gg_magic(pl.q_major ? Pn : Qn), gg_magic(tiles_w), gg_magic(tiles_h), gg_magic(pl.nch_stage), gg_magic(nch_last), Qn,
                          gg_magic(pl.nch_stage_s), gg_magic(nch_s_last), pl.nstage_s, pl.nch_stage_s};
-    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3, SK, NS>), grid, dim3(512), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
+    hipLaunchKernelGGL((conv_box2d_kernel<TWI, MT, CT, UP, K3, SK, NS>), grid, dim3(GG_BOX_NW * 64), (size_t)pl.smem, stream, p, tiles_h, tiles_w, pl.nstage,
                        pl.nch_stage, pl.gn_bytes, pl.q_major, (int)grid.x, mg);
     GG_CHECK_LAUNCH();
     return GG_OK;
