@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_lean_kernel(const bf16_t *__
 {
     s1 = gg_pin(s1); C1 = gg_pin(C1); acc1 = gg_pin(acc1); s2 = gg_pin(s2); C2 = gg_pin(C2); acc2 = gg_pin(acc2); S = gg_pin(S);
     C_logical = gg_pin(C_logical); gamma = gg_pin(gamma); beta = gg_pin(beta); pmagic = gg_pin(pmagic);
+    GG_GSTAMP(0);
     typedef __attribute__((ext_vector_type(2))) long long i64x2;
     const int C = C1 + C2, P = C >> 3;
     const int tid = threadIdx.x, n = blockIdx.y;
@@ -606,7 +607,9 @@ __global__ __launch_bounds__(256) void gn_apply_acc_lean_kernel(const bf16_t *__
         }
     }
     const int cpg = C_logical >> 5;
+    GG_GSTAMP(1);
     __syncthreads();
+    GG_GSTAMP(2);
     if (tid < 32) {
         i64x2 t = i64x2{0, 0};
         for (int j = 0; j < cpg; ++j) t += csum[tid * cpg + j];
@@ -618,8 +621,10 @@ __global__ __launch_bounds__(256) void gn_apply_acc_lean_kernel(const bf16_t *__
         if (var < 0.0) var = 0.0;
         gmean[tid] = (float)mean;
         grstd[tid] = rsqrtf((float)var + eps);
+        GG_GSTAMP(3);
     }
     __syncthreads();
+    GG_GSTAMP(4);
     if (!live) return;
     const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
     const bf16x8 v = __builtin_bit_cast(bf16x8, pv);
@@ -637,6 +642,7 @@ __global__ __launch_bounds__(256) void gn_apply_acc_lean_kernel(const bf16_t *__
         y[j] = (bf16_t)t;
     }
     *reinterpret_cast<bf16x8 *>(out + ((unsigned)n * (unsigned)S + (unsigned)row) * (unsigned)C + (unsigned)c0) = y;
+    GG_GSTAMP(5);
 }
 
 extern "C" int gg_groupnorm_apply_acc(const void *src1, int32_t C1, const int64_t *acc1, const void *src2, int32_t C2,

@@ -1,6 +1,6 @@
 """Phase stamps of gn_apply_acc_kernel (diagnostic build: hipcc -DGG_GN_STAMPS of gg_norm.hip linked into tools/experiments/ab/libG.so):
    python tools/experiments/probe_gn_stamps.py C HW
-Prints over all blocks the s_memrealtime (10 ns ticks) of thread 0 at: entry (arguments pinned), loads issued, first accumulator landed,
+(lean kernel; GG_OLD_KERNEL=1 with a -DGG_GN_APPLY_ACC_LEAN=0 build for the table kernel)  Prints over all blocks the s_memrealtime (10 ns ticks) of thread 0 at: entry (arguments pinned), loads issued, first accumulator landed,
 group sums folded, statistics done, table written, stored -- relative to the first block's entry."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -35,7 +35,8 @@ buf = np.zeros(nb * 8, dtype=np.uint64)
 assert raw.gg_gn_stamps_read(buf.ctypes.data_as(C.c_void_p), nb * 8) == 0
 t = buf.reshape(nb, 8).astype(np.float64)
 t0 = t[:, 0].min()
-names = ["entry (args pinned)", "loads issued", "first acc landed", "group sums folded", "statistics done", "table written", "stored"]
+names = ["entry (args pinned)", "loads issued, sums parked", "after barrier 1", "group statistics done", "after barrier 2", "stored"]
+if os.environ.get("GG_OLD_KERNEL"): names = ["entry (args pinned)", "loads issued", "first acc landed", "group sums folded", "statistics done", "table written", "stored"]
 print(f"gn_apply_acc C={Cc} @{HW}^2: {nb} blocks, event time {e0.elapsed_time(e1) * 1e3:.1f} us; us after the first block's entry:")
 for i, nm in enumerate(names):
     v = (t[:, i] - t0) / 100.0
