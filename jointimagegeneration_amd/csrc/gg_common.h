@@ -52,6 +52,18 @@ __device__ __forceinline__ T gg_pin(T v)
     }
 }
 
+// Weights of the latent UNet's batch-1 convs are read ONCE per forward (535 MB per forward against 8 x 4 MB of L2 and 256 MB of MALL):
+// loaded with the default policy they evict the activations, accumulators and parameters the NEXT kernels are about to read.
+// GG_STREAM_LOAD marks them non-temporal (measured: tools/experiments/README.md, "non-temporal weight loads").
+#ifndef GG_STREAM_WEIGHTS
+#define GG_STREAM_WEIGHTS 1
+#endif
+#if GG_STREAM_WEIGHTS
+#define GG_STREAM_LOAD(P) __builtin_nontemporal_load(P)
+#else
+#define GG_STREAM_LOAD(P) (*(P))
+#endif
+
 // Integer division is a ~30 (32-bit) to ~150 (64-bit) instruction sequence on this ISA, and a wave issues its instructions one by
 // one: in the launch-bound kernels of the latent UNet an index division IS microseconds.
 // gg_fastdiv: n / d through one multiply-high; exact for 0 <= n, n * d < 2^32 (gg_magic_u32 returns 0 when that does not hold or

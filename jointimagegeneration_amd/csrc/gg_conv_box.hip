@@ -327,8 +327,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                 for (int u = 0; u < 3; ++u)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        if constexpr (NS == 1) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);
-                        else if (wact) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512);     // (foreign rows: stale registers)
+                        if constexpr (NS == 1) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));
+                        else if (wact) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));     // (foreign rows: stale registers)
                     }
                 const int adv = (lidx + 1 < q1) ? 1 : 0;
                 lidx += adv;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                 for (int u = 0; u < 4; ++u) {
                     const bf16_t *tile = wbase + ((long long)(cbase + lc) << 10) + wl0;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
                     lc += (lc + 1 < q1) ? 1 : 0;
                 }
             }
@@ -619,8 +619,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                     const bf16_t *tile = wsk + ((long long)(cbase + lc) << 10) + wl0;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        if constexpr (NS == 1) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
-                        else if (wact) a[u][ct] = *reinterpret_cast<const bf16x8 *>(tile + ct * 512);
+                        if constexpr (NS == 1) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
+                        else if (wact) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
                     }
                     lc += (lc + 1 < q1) ? 1 : 0;
                 }
