@@ -89,6 +89,12 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
     mg.nch_s = mg_arg.nch_s; mg.nch_s_last = mg_arg.nch_s_last; mg.nstage_s = mg_arg.nstage_s; mg.nch_stage_s = mg_arg.nch_stage_s;
     // an MFMA position tile (16 positions) is RPT rows x TWI columns: one 16-wide row, 2 x 8 or 4 x 4 (deep UNet levels)
     constexpr int TW = TWI, NW = GG_BOX_NW, NTH = NW * 64;
+    // Weight tiles of the 8- / 4-wide shapes (the 8x8 / 4x4 levels: 400 of the 535 MB of weights, each byte read by one to four
+    // workgroups per forward) by non-temporal loads (gg_common.h): with the default policy they evict what the next kernels read.
+    // Where many position tiles share a weight slice (64x64 .. 16x16) the default policy keeps their L2 hits.  Per captured forward:
+    // none 1385 us, every shape 1330, 8- / 4-wide only 1308 (N = 1 @64x64); N = 4 @32x32 1435 -> 1365; N = 8 @64x64 3866 -> 3878.
+    constexpr bool WNT = TWI < 16;
+    auto WLOAD = [](const auto *ptr) { if constexpr (WNT) return GG_STREAM_LOAD(ptr); else return *ptr; };
     constexpr int RPT = 16 / TWI;
     constexpr int TH = MT * RPT;                      // output rows of the workgroup
     // Weight trips (4 k-steps each) kept in flight per wave: measured on the latent-UNet forward (same box, hipGraph replay):
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                 for (int u = 0; u < 3; ++u)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        if constexpr (NS == 1) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));
-                        else if (wact) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));     // (foreign rows: stale registers)
+                        if constexpr (NS == 1) a[u][ct] = WLOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));
+                        else if (wact) a[u][ct] = WLOAD(reinterpret_cast<const bf16x8 *>(tile + u * kws + ct * 512));     // (foreign rows: stale registers)
                     }
                 const int adv = (lidx + 1 < q1) ? 1 : 0;
                 lidx += adv;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                 for (int u = 0; u < 4; ++u) {
                     const bf16_t *tile = wbase + ((long long)(cbase + lc) << 10) + wl0;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
+                    for (int ct = 0; ct < CT; ++ct) a[u][ct] = WLOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
                     lc += (lc + 1 < q1) ? 1 : 0;
                 }
             }
@@ -619,8 +625,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                     const bf16_t *tile = wsk + ((long long)(cbase + lc) << 10) + wl0;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        if constexpr (NS == 1) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
-                        else if (wact) a[u][ct] = GG_STREAM_LOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
+                        if constexpr (NS == 1) a[u][ct] = WLOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
+                        else if (wact) a[u][ct] = WLOAD(reinterpret_cast<const bf16x8 *>(tile + ct * 512));
                     }
                     lc += (lc + 1 < q1) ? 1 : 0;
                 }

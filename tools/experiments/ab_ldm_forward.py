@@ -15,8 +15,9 @@ dev = torch.device("cuda:0")
 u = UNetModel(dims=2, image_size=512, in_channels=8, out_channels=4, model_channels=160, attention_resolutions=[8, 4, 2],
               num_res_blocks=2, channel_mult=[1, 2, 4, 4, 5], num_head_channels=32).eval()
 randomize_parameters(u, 1024, "ldm."); u = u.to(dev)
-x = CL(torch.randn(1, 1, 64, 64, 32, device=dev).bfloat16(), 8)
-row = u.time_bias_rows(torch.full((1,), 981.0, device=dev))
+NB, RR = int(os.environ.get("GG_N", 1)), int(os.environ.get("GG_R", 64))          # batch / latent size (default: the C5 slice, N = 1 @64x64)
+x = CL(torch.randn(NB, 1, RR, RR, 32, device=dev).bfloat16(), 8)
+row = u.time_bias_rows(torch.full((NB,), 981.0, device=dev))
 u.forward_cl(x, row); torch.cuda.synchronize()
 g = ops.capture_graph(lambda: u.forward_cl(x, row))
 for _ in range(5): g.replay()
@@ -27,4 +28,4 @@ for rep in range(3):
     for _ in range(100): g.replay()
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 100 * 1e3)
-print(f"{os.path.basename(sys.argv[1])}: " + " / ".join(f"{t:.1f}" for t in ts) + " us per forward", flush=True)
+print(f"{os.path.basename(sys.argv[1])} N={NB} @{RR}: " + " / ".join(f"{t:.1f}" for t in ts) + " us per forward", flush=True)
