@@ -12,7 +12,7 @@ echo "bench pass rc=$?"
 # 2. one eager latent-UNet forward, per-kernel timeline
 GG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats -d $OUT/ldm -o ldm -- python3 tools/perf_probe.py ldm > $OUT/ldm_probe.log 2>&1
 echo "ldm pass rc=$?"
-python3 tools/ldm_timeline.py $(ls $OUT/ldm/*/ldm_results.db | head -1) --all > $OUT/ldm_unet_forward_timeline_eager.txt 2>&1
+python3 tools/ldm_timeline.py $(find $OUT/ldm -name "ldm_results.db" | head -1) --all > $OUT/ldm_unet_forward_timeline_eager.txt 2>&1
 # 3. CCDM forward @128^3: kernel stats, FETCH / WRITE passes, one SQ pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ccdm -o ccdm -- python3 tools/perf_probe.py ccdm128 > $OUT/ccdm_probe.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 tools/perf_probe.py ccdm128 > /dev/null 2>&1
