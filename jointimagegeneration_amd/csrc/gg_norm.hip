@@ -116,6 +116,29 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 // Small-tensor fast path: ONE launch. Block (g, n) reduces its group's S x cpg elements (fp32 per thread, fp64 tree),
 // then writes the folded scale/shift of its channels. Used when N*S*C is small enough that launch latency, not HBM,
 // is the cost (LDM latent UNet, deep CCDM levels).
+// x + (x of the DPP-selected lane) in fp64: two DPP moves + one add, no LDS round trip (a 64-bit __shfl_xor is two ds_bpermute, ~150 cycles
+// of dependent latency per butterfly step: six steps were ~0.4 us of a 3.4 us kernel)
+template <int CTRL>
+__device__ __forceinline__ double gg_dpp_add_f64(double x)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over the 64 lanes of a wave, fixed order (deterministic): the 16 lanes of a row by DPP (quad xor 1, quad xor 2, half-row mirror,
+// row mirror), the four rows by two xor shuffles
+__device__ __forceinline__ double gg_wave_sum_f64(double x)
+{
+    x = gg_dpp_add_f64<0xB1>(x);
+    x = gg_dpp_add_f64<0x4E>(x);
+    x = gg_dpp_add_f64<0x141>(x);
+    x = gg_dpp_add_f64<0x140>(x);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
 __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__restrict__ s1, int C1, const bf16_t *__restrict__ s2,
                                                              int C2, long long S, int C_logical, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, float eps, float *__restrict__ scale,
@@ -153,12 +176,7 @@ __global__ __launch_bounds__(256) void gn_stats_small_kernel(const bf16_t *__res
         }
     }
     // fixed-order reduction: fp64 butterfly inside each wave (6 steps), then the 4 waves through LDS: one barrier, not eight
-    double da = (double)a, db = (double)b;
-#pragma unroll
-    for (int x = 1; x < 64; x <<= 1) {
-        da += __shfl_xor(da, x);
-        db += __shfl_xor(db, x);
-    }
+    const double da = gg_wave_sum_f64((double)a), db = gg_wave_sum_f64((double)b);
     __shared__ double ra[4], rb[4];
     if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
     __syncthreads();
@@ -234,12 +252,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const bf16_t *__res
             }
         }
     }
-    double da = (double)a, db = (double)b;
-#pragma unroll
-    for (int x = 1; x < 64; x <<= 1) {
-        da += __shfl_xor(da, x);
-        db += __shfl_xor(db, x);
-    }
+    const double da = gg_wave_sum_f64((double)a), db = gg_wave_sum_f64((double)b);
     __shared__ double ra[4], rb[4];
     if ((tid & 63) == 0) { ra[tid >> 6] = da; rb[tid >> 6] = db; }
     __syncthreads();
