@@ -713,8 +713,9 @@ __global__ __launch_bounds__(256) void gn_scale_shift_acc_kernel(const long long
     typedef __attribute__((ext_vector_type(2))) long long i64x2;
     const int smax = stripes1 > stripes2 ? stripes1 : stripes2;
     long long sa = 0, sb = 0;
+    const float rcpg = __builtin_amdgcn_rcpf((float)cpg);
     for (int i = tid; i < cpg * smax; i += 256) {
-        const int k = i / cpg, c = g * cpg + (i - k * cpg);
+        const int k = gg_div_small(i, rcpg), c = g * cpg + (i - k * cpg);          // (i < 64 * 32: exact; an integer division is ~30 instructions)
         const bool first = c < C1;
         const int st = first ? stripes1 : stripes2, Cs = first ? C1 : C2, cc = first ? c : c - C1;
         if (k < st) {
@@ -728,11 +729,13 @@ __global__ __launch_bounds__(256) void gn_scale_shift_acc_kernel(const long long
     __syncthreads();
     const double a = (double)(long long)gacc[0] * (1.0 / GG_ACC_SUM_SCALE_D);
     const double b = (double)(long long)gacc[1] * (1.0 / GG_ACC_SQ_SCALE_D);
-    const double cnt = (double)S * (double)cpg;
-    const double mean = a / cnt;
-    double var = b / cnt - mean * mean;
+    // (as gn_apply_acc_kernel: fp32 reciprocal of the exact count + one Newton step in fp64, v_rsq_f32; the fp64 divisions and the fp64
+    //  square root were ~150 instructions on the critical path of a 7 us kernel, 27-29 launches per CCDM forward / AE pass)
+    const double cnt = (double)S * (double)cpg; double inv = (double)(1.0f / (float)cnt); inv = inv * (2.0 - cnt * inv);
+    const double mean = a * inv;
+    double var = b * inv - mean * mean;
     if (var < 0.0) var = 0.0;
-    const float fmean = (float)mean, frstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean, frstd = rsqrtf((float)var + eps);
     if (tid < cpg) {
         const int c = g * cpg + tid;
         const float sc = frstd * gmm;

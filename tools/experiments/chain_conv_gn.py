@@ -52,7 +52,10 @@ def pair_chain():
             h = ops.groupnorm_apply_acc(h, gam, bet, 1e-5, True)
         ops.stats_end(dev)
     return f
-tc0 = timeit(conv_chain(False), L); tc1 = timeit(conv_chain(True), L)
+ops.GN_ACC = False
+tc0 = timeit(conv_chain(False), L)              # no statistics epilogue at all (no accumulator atomics)
+ops.GN_ACC = True
+tc1 = timeit(conv_chain(True), L)
 try:
     tg = timeit(gn_chain(), L)
 except Exception as e:
