@@ -9,6 +9,9 @@
 //   epilogue                  lane holds 4 consecutive d of one query -> 8-byte stores
 #include "gg_common.h"
 
+#ifndef GG_ATTN_WS2
+#define GG_ATTN_WS2 1          /* in-workgroup key split for under-filled grids (A/B: tools/experiments) */
+#endif
 struct AttnParams {
     int N, heads, Tq, Tkv;
     long long ldq, hsq, ldk, hsk, ldv, hsv, ldo, hso;
@@ -32,9 +35,14 @@ __device__ __forceinline__ int swz_row(int row, int chunk)
     else return chunk ^ (row & 15);
 }
 
-template <int D, int KT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
+// WS = 2: key split INSIDE the workgroup (8 waves): waves 0-3 and waves 4-7 take the same 64 queries and one half of the keys each, with
+// K/V tiles of their own, and merge their online-softmax states through LDS at the end.  For under-filled grids with long key loops (the
+// latent UNet's 32x32 attention at batch 1: 160 workgroups, T = 1024: 8 softmax steps of 128 keys per wave, the kernel is bound by that
+// serial chain): half the steps per wave for the same staging work per thread.
+template <int D, int KT, int WS = 1>
+__global__ __launch_bounds__(256 * WS) void attn_kernel(const AttnParams p)
 {
+    static_assert(WS == 1 || (WS == 2 && D < 256), "in-workgroup key split: register-staged tiles only");
     constexpr int CH = D / 8;          // 16-byte chunks per row
     constexpr int ROWB = D * 2;
     constexpr int KS = D / 32;         // k-steps of the S^T product
@@ -44,16 +52,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     // per K or V row), hand-counted vmcnt.  (Inline-asm DMA: the compiler would drain all LDS-DMA before every ds_read.)
     constexpr bool DMA = D >= 256;
     constexpr int TILEB = 2 * KT * ROWB;               // K tile + V tile
-    __shared__ __attribute__((aligned(1024))) char smem[(DMA ? 2 : 1) * TILEB];
-    char *ksm = smem, *vsm = smem + KT * ROWB;
+    __shared__ __attribute__((aligned(1024))) char smem[(DMA ? 2 : WS) * TILEB];
+    const int grp = WS == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;      // key half of this wave group
+    char *ksm = smem + grp * TILEB, *vsm = ksm + KT * ROWB;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;            // (thread index inside the wave group)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform (LDS-DMA destinations live in M0)
     const int fr = lane & 15, g = lane >> 4;
     const int n = blockIdx.z, h = blockIdx.y;
     const int qt = p.ksplit > 1 ? blockIdx.x / p.ksplit : blockIdx.x, ksp = p.ksplit > 1 ? blockIdx.x - qt * p.ksplit : 0;
     const int q0 = qt * 64 + wave * 16;
-    const int kbeg = ksp * p.kchunk, kend = (p.ksplit > 1 && kbeg + p.kchunk < p.Tkv) ? kbeg + p.kchunk : p.Tkv;     // kchunk % KT == 0
+    int kbeg = ksp * p.kchunk, kend = (p.ksplit > 1 && kbeg + p.kchunk < p.Tkv) ? kbeg + p.kchunk : p.Tkv;     // kchunk % KT == 0
+    int ntile = (kend - kbeg + KT - 1) / KT;                       // tiles of this workgroup's key range
+    if constexpr (WS == 2) {                                       // both groups walk the SAME number of tiles (whole-workgroup barriers)
+        ntile = (ntile + 1) >> 1;
+        kbeg += grp * ntile * KT;
+        const int ke = kbeg + ntile * KT;
+        kend = ke < kend ? ke : kend;                              // (the second group's range may be short or empty: masked / skipped steps)
+    }
 
     // Q fragments (B operand: col = query fr, k = 8g + j)
     bf16x8 qf[KS];
@@ -111,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
     if (DMA) stage_dma(kbeg, 0);
     if (!DMA && PREFETCH) fetch(kbeg);
     int tile = 0;
-    for (int key0 = kbeg; key0 < kend; key0 += KT, ++tile) {
+    for (int key0 = kbeg; tile < ntile; key0 += KT, ++tile) {
         if (DMA) {
             const bool more = key0 + KT < kend;
             if (more) stage_dma(key0 + KT, (tile + 1) & 1);          // the other buffer: last read one tile ago, barrier since
@@ -234,6 +250,30 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p)
         }
     }
 
+    if constexpr (WS == 2) {
+        // merge the two key halves: out = (w0 o0 + w1 o1) / (w0 l0 + w1 l1), w = 2^(m - max m) (the exact combination, as attn_merge_kernel)
+        __syncthreads();                                   // every wave is done with its tiles
+        float *st = reinterpret_cast<float *>(smem);       // [DT * 4 + 2][256]
+        if (grp == 1) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(dt * 4 + r) * 256 + tid] = o[dt][r];
+            st[(DT * 4) * 256 + tid] = m_run;
+            st[(DT * 4 + 1) * 256 + tid] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = st[(DT * 4) * 256 + tid], l1 = st[(DT * 4 + 1) * 256 + tid];
+        const float mm = fmaxf(m_run, m1);
+        const float w0 = __builtin_amdgcn_exp2f(m_run - mm), w1 = __builtin_amdgcn_exp2f(m1 - mm);      // (m1 = -inf for an empty half: w1 = 0)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] = o[dt][r] * w0 + st[(dt * 4 + r) * 256 + tid] * w1;
+        l_run = l_run * w0 + l1 * w1;
+        m_run = mm;
+    }
     const int qi = q0 + fr;
     if (p.ksplit > 1) {
         if (qi < p.Tq) {          // unnormalised partial state of this key range
@@ -314,7 +354,13 @@ static int launch_attn(AttnParams p, const gg_attention_desc *d, hipStream_t str
     p.ws_o = (float *)d->workspace;
     p.ws_ml = p.ws_o ? p.ws_o + rows * D : nullptr;
     dim3 grid((unsigned)(qtiles * ks), (unsigned)p.heads, (unsigned)p.N);
-    hipLaunchKernelGGL((attn_kernel<D, KT>), grid, dim3(256), 0, stream, p);
+    // in-workgroup key split: under-filled grids with at least four K/V tiles per workgroup (the 32x32 attention blocks at batch 1)
+    bool ws2 = false;
+    if constexpr (D < 256) ws2 = GG_ATTN_WS2 && ks == 1 && blocks <= 256 && p.Tkv >= 4 * KT;
+    if constexpr (D < 256) {
+        if (ws2) hipLaunchKernelGGL((attn_kernel<D, KT, 2>), grid, dim3(512), 0, stream, p);
+    }
+    if (!ws2) hipLaunchKernelGGL((attn_kernel<D, KT>), grid, dim3(256), 0, stream, p);
     GG_CHECK_LAUNCH();
     if (ks > 1) {
         const long long total = (long long)p.N * p.heads * p.Tq * (D / 4);

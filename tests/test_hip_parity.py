@@ -597,7 +597,8 @@ def test_feed_forward_projection_with_geglu_epilogue(dev, shape, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("cfg", [(2, 2, 32, 128), (1, 8, 32, 512), (2, 3, 32, 64), (1, 1, 64, 64), (1, 1, 512, 96), (1, 1, 384, 40), (1, 4, 128, 70)],
+@pytest.mark.parametrize("cfg", [(2, 2, 32, 128), (1, 8, 32, 512), (2, 3, 32, 64), (1, 1, 64, 64), (1, 1, 512, 96), (1, 1, 384, 40), (1, 4, 128, 70),
+                                 (1, 10, 32, 1024), (1, 3, 32, 1100), (1, 2, 64, 300), (1, 1, 128, 333)],      # (in-workgroup key split: T >= 4 key tiles, under-filled grid; ragged halves)
                          ids=lambda c: f"N{c[0]}h{c[1]}d{c[2]}T{c[3]}")
 def test_attention_legacy_layout(dev, cfg):
     from jointimagegeneration_amd import ops
