@@ -36,6 +36,9 @@
 #ifndef GG_BOX_NW
 #define GG_BOX_NW 8                          /* waves per workgroup (8: two per SIMD; 4: one per SIMD -- A/B: tools/experiments) */
 #endif
+#ifndef GG_BOX_STRIDE2
+#define GG_BOX_STRIDE2 1                     /* stride-2 3x3 convs (UNet Downsample) on the box kernel (A/B: tools/experiments) */
+#endif
 #ifndef GG_BOX_COUT_SUBSPLIT
 #define GG_BOX_COUT_SUBSPLIT 1               /* 3x3 convs of the 8x8 / 4x4 levels: 2 or 4 workgroups per 16-cout tile (A/B: tools/experiments) */
 #endif
@@ -107,8 +110,14 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
     // the first DMA, ~2.8 us until the box has landed, ~2 us of k-loop, 1.2 us of combine and epilogue; the split buys ~0.5 us).
     constexpr int NTRIP = 2 * NS * (8 / NW);   // (3x3 with (kh, chunk) units: 2 units = 6 k-steps in flight 1511 us per forward, 3 units 1514)
     constexpr int PADK = K3 ? 1 : 0, NTAPS = K3 ? 9 : 1;      // 3x3 pad 1, or 1x1 (the box is then the tile itself)
-    constexpr int HH = UP ? TH / 2 + 2 : TH + 2 * PADK;
-    constexpr int HW = UP ? TW / 2 + 2 : TW + 2 * PADK;
+    // UP: 0 plain, 1 fused nearest x2 upsample, 2 STRIDE 2 (the UNet's Downsample convs: 3x3, pad 1): the box is (2 TH + 1) x (2 TW + 1)
+    // input positions, its columns stored de-interleaved inside a line (slots 0 .. TW: even columns, TW + 1 .. 2 TW: odd columns), so
+    // that the 16 lanes of an operand read (input columns 2 c + kw) touch consecutive slots as in the stride-1 box
+    constexpr bool S2 = UP == 2;
+    static_assert(!S2 || K3, "stride 2: 3x3 only");
+    constexpr int HH = UP == 1 ? TH / 2 + 2 : S2 ? 2 * TH + 1 : TH + 2 * PADK;
+    constexpr int HW = UP == 1 ? TW / 2 + 2 : S2 ? 2 * TW + 1 : TW + 2 * PADK;
+    auto colof = [](int hw) -> int { return S2 ? (hw <= TW ? 2 * hw : 2 * (hw - TW - 1) + 1) : hw; };       // input column of a line slot
     constexpr int NROWS = HH * HW;
     constexpr int NRB = (NROWS + 15) / 16;            // 1 KiB DMA blocks (16 rows) per chunk plane
     constexpr int PLANE = NRB * 1024;                 // one 32-channel chunk of the box
@@ -119,8 +128,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
     // 60 per k-step at 12 position tiles, MORE issue cycles than the k-step's 12 MFMAs (timing ablation: 1.76 -> 1.70 ms per
     // latent-UNet forward).  No such map exists for the upsampled 8- / 4-wide boxes; they keep the row-based one (2 launches per
     // forward), and so do 1x1 boxes, where the row-based map is already a lane constant.
-    constexpr bool LINE_SWZ = K3 && (TWI == 16 || !UP);
-    constexpr unsigned FMASK = TWI == 16 ? (UP ? 0x3C0u : 0xFC30u) : TWI == 8 ? 0xCCu : 0x0Cu;
+    constexpr bool LINE_SWZ = K3 && !S2 && (TWI == 16 || !UP);
+    constexpr unsigned FMASK = TWI == 16 ? (UP == 1 ? 0x3C0u : 0xFC30u) : TWI == 8 ? 0xCCu : 0x0Cu;
     constexpr bool LANE_ADDR = LINE_SWZ || !K3;       // operand address = lane constant + uniform + immediate
     auto bsw = [&](int row, int hw) -> int { return LINE_SWZ ? (int)((FMASK >> hw) & 1u) << 1 : (row >> 1) & 2; };
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
     const int th = t1 - n * tiles_h;
     const int h0 = th * TH, w0 = tw * TW;
     const int g = CT == 2 ? by : by >> 1, half = CT == 2 ? 0 : by & 1;
-    const int ih0 = UP ? h0 / 2 - 1 : h0 - PADK;
-    const int iw0 = UP ? w0 / 2 - 1 : w0 - PADK;
+    const int ih0 = UP == 1 ? h0 / 2 - 1 : S2 ? 2 * h0 - 1 : h0 - PADK;
+    const int iw0 = UP == 1 ? w0 / 2 - 1 : S2 ? 2 * w0 - 1 : w0 - PADK;
 
     // final pass: thread -> f32x4 slot (tid & 63) of slices (tid >> 6) + 8k; with CT | 8 its 4 couts are the same for every k,
     // so the bias is fetched here, a whole kernel ahead of its use
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
         auto setup = [&](int rb) {
             const int row = rb * 16 + lrow;
             const int hh = row / HW, hw = row - hh * HW;
-            const int ih = ih0 + hh, iw = iw0 + hw;
+            const int ih = ih0 + hh, iw = iw0 + colof(hw);
             inr = row < NROWS;
             valid = inr && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const unsigned pos = valid ? (unsigned)(ih * p.W + iw) : 0u;
@@ -297,8 +306,8 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                 const int pos_rh = frh / TWI, pos_ch = frh % TWI;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int rwk = UP ? ((pos_ch + k + 1) >> 1) : (pos_ch + k);
-                    lane_off[k] = (UP ? 0 : pos_rh * (HW * 64)) + rwk * 64 + ((fqh ^ bsw(0, rwk)) * 16);
+                    const int rwk = UP == 1 ? ((pos_ch + k + 1) >> 1) : (pos_ch + k);
+                    lane_off[k] = (UP == 1 ? 0 : pos_rh * (HW * 64)) + rwk * 64 + ((fqh ^ bsw(0, rwk)) * 16);
                 }
             } else if constexpr (!K3) {
                 lane_off[0] = frh * 64 + ((fqh ^ ((frh >> 1) & 2)) * 16);       // row = 16 * tile + fr: the row-based map only sees fr
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                     for (int rbk = 0; rbk < NRB; ++rbk) {
                         const int row = rbk * 16 + lrowh;
                         const int hh = row / HW, hw = row - hh * HW;
-                        const int ih = ih0 + hh, iw = iw0 + hw;
+                        const int ih = ih0 + hh, iw = iw0 + colof(hw);
                         if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) xform(box + c * PLANE + rbk * 1024 + laneh * 16, sc0, sc1, sh0, sh1);
                     }
                 }
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                     const int c = unit / NRB, rbk = unit - c * NRB;
                     const int row = rbk * 16 + lrowh;
                     const int hh = row / HW, hw = row - hh * HW;
-                    const int ih = ih0 + hh, iw = iw0 + hw;
+                    const int ih = ih0 + hh, iw = iw0 + colof(hw);
                     if (row < NROWS && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
                         const int q = lsloth ^ bsw(row, hw);
                         const float *sc = gsc + c * 32 + q * 8, *sh = sc + gsh;
@@ -504,11 +513,12 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
                         xf[tt] = *reinterpret_cast<const bf16x8 *>(((tt & 1) ? po : pe) + (tt >> 1) * (HW * 64));
                 }
             } else {
-                const int rwk = UP ? ((pos_c + kw + 1) >> 1) : (pos_c + kw);     // per-lane column of the operand row
+                // per-lane column slot of the operand row (stride 2: input column 2 c + kw -> even slot c + kw / 2, or odd slot TW + 1 + c)
+                const int rwk = UP == 1 ? ((pos_c + kw + 1) >> 1) : S2 ? ((kw & 1) ? TW + 1 + pos_c : pos_c + (kw >> 1)) : (pos_c + kw);
 #pragma unroll
                 for (int tt = 0; tt < MT; ++tt) {
                     const int orow = tt * RPT + pos_r;
-                    const int hh = UP ? ((orow + kh + 1) >> 1) : orow + kh;
+                    const int hh = UP == 1 ? ((orow + kh + 1) >> 1) : S2 ? 2 * orow + kh : orow + kh;
                     const int row = hh * HW + rwk;
                     xf[tt] = *reinterpret_cast<const bf16x8 *>(plane + row * 64 + swz64(row, fq) * 16);
                 }
@@ -800,7 +810,8 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
 {
     constexpr long long max_blocks = 1024, lds_cap = 131072;     // <= 4 rounds of 256 workgroups; box + GroupNorm rows <= 128 KiB
     const bool k3 = p.kh == 3 && p.kw == 3 && p.pad == 1, k1 = p.kh == 1 && p.kw == 1 && p.pad == 0 && !p.upsample;
-    if (!(p.kd == 1 && p.D == 1 && p.stride == 1 && (k3 || k1))) return false;
+    const bool s2 = GG_BOX_STRIDE2 && p.stride == 2 && k3 && !p.upsample && p.skip_C1 == 0;      // the UNet's Downsample convs
+    if (!(p.kd == 1 && p.D == 1 && (p.stride == 1 || s2) && (k3 || k1))) return false;
     const int halo = k3 ? 2 : 0;
     // 1x1: only where the grid is under-filled (measured: 8x8 4.2 vs 8.6 us on the tiny-M kernel, but 64x64 12.0 vs 7.8 us on gather5)
     constexpr long long k1_max_m = 256;
@@ -820,7 +831,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
         if ((p.upsample && (TH & 1)) || TH > p.Ho) continue;
         if (TWI != 16 && (MT == 12 || MT == 6 || MT == 3 || p.Ho % TH)) continue;
         if ((TWI == 16 && MT == 1) || (TWI == 8 && MT == 8) || (TWI == 4 && MT != 1)) continue;   // instantiated shapes only
-        const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
+        const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : s2 ? (2 * TH + 1) * (2 * TWI + 1) : (TH + halo) * (TWI + halo);
         const long long boxb = (long long)rows * p.nchunk * 64;
         for (int CT : {2, 1}) {
             const long long blocks = (long long)p.N * ((p.Ho + TH - 1) / TH) * (p.Wo / TWI) * (p.Cout_pad / (16 * CT));
@@ -833,7 +844,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
             if (!bMT || cost < best * 0.97) { best = cost; bMT = MT; bCT = CT; bNS = 1; }
             // cout sub-split (weight-bound 3x3 convs of the 8x8 / 4x4 levels; instantiated shapes only): NS workgroups per 16-cout tile,
             // each taking in 1 / NS of its weight rows and the whole box
-            if (GG_BOX_COUT_SUBSPLIT && CT == 1 && k3 && !p.upsample && ((TWI == 4 && MT == 1) || (TWI == 8 && MT == 2)))
+            if (GG_BOX_COUT_SUBSPLIT && CT == 1 && k3 && !p.upsample && !s2 && ((TWI == 4 && MT == 1) || (TWI == 8 && MT == 2)))
                 for (int NS : {2, 4}) {
                     if (blocks * NS > 256) continue;                       // one round only
                     const double cs = (double)(wbytes16 / NS + boxb) * (1.0 + 0.15 * (double)(nst - 1));
@@ -843,7 +854,7 @@ static bool plan_box(const ConvParams &p, BoxPlan &pl)
     }
     if (!bMT) return false;                                          // filled grids: the halo / wide-tile kernels win
     const int MT = bMT, CT = bCT, NS = bNS, TH = MT * RPT;
-    const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : (TH + halo) * (TWI + halo);
+    const int rows = p.upsample ? (TH / 2 + 2) * (TWI / 2 + 2) : s2 ? (2 * TH + 1) * (2 * TWI + 1) : (TH + halo) * (TWI + halo);
     const long long plane = (long long)((rows + 15) / 16) * 1024;   // whole 16-row DMA blocks
     long long cap = lds_cap / plane;
     if (cap < 1) return false;
@@ -965,6 +976,7 @@ int gg_conv_box_try(const ConvParams &p, hipStream_t stream)
     if (stream == (hipStream_t)-1) return GG_OK;
     if (p.skip_C1 > 0) return pl.CT == 2 ? dispatch_box<2, 0, 1, 1>(p, pl, stream) : dispatch_box<1, 0, 1, 1>(p, pl, stream);     // (plan_box: 3x3, no upsample)
     if (p.kh == 1) return pl.CT == 2 ? dispatch_box<2, 0, 0>(p, pl, stream) : dispatch_box<1, 0, 0>(p, pl, stream);
+    if (p.stride == 2) return pl.CT == 2 ? dispatch_box<2, 2, 1>(p, pl, stream) : dispatch_box<1, 2, 1>(p, pl, stream);
     if (pl.CT == 2) return p.upsample ? dispatch_box<2, 1, 1>(p, pl, stream) : dispatch_box<2, 0, 1>(p, pl, stream);
     return p.upsample ? dispatch_box<1, 1, 1>(p, pl, stream) : dispatch_box<1, 0, 1>(p, pl, stream);
 }

@@ -210,6 +210,30 @@ def test_conv_gather5_two_source_prologue_residual(dev):
     assert rel_err(ops.from_cl(o, 2), O.conv(bf(xs), bf(w2), stride=2, padding=1)) < 1e-2
 
 
+BOX_S2_CASES = [(1, 160, 160, (64, 64)), (1, 320, 320, (32, 32)), (1, 640, 640, (16, 16)), (1, 640, 640, (8, 8)), (2, 96, 64, (16, 16)),
+                (1, 64, 40, (24, 16)), (1, 64, 64, (10, 8)), (3, 32, 96, (12, 32))]
+
+
+@pytest.mark.parametrize("case", BOX_S2_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3][0]}x{c[3][1]}" for c in BOX_S2_CASES])
+def test_conv_box_stride2_matches_oracle(dev, case):
+    """UNet Downsample convs (3x3, stride 2, pad 1; unet.py Downsample / openaimodel.py:143-163) on the box-resident kernel: de-interleaved
+    box columns, odd and ragged extents, batches, padded couts."""
+    from jointimagegeneration_amd import ops
+    N, Cin, Cout, sp = case
+    g = torch.Generator().manual_seed(Cin + Cout + sp[0])
+    x = torch.randn((N, Cin) + sp, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = O.conv(bf(x), bf(w), b, stride=2, padding=1)
+    xcl = ops.to_cl(x.to(dev))
+    out = ops.conv(xcl, ops.pack_conv_weight(w.to(dev), xcl.Cpad), ops.pad_bias(b.to(dev), Cout, dev), Cout, k=(1, 3, 3), stride=2, pad=1)
+    got = ops.from_cl(out, 2).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-2, rel_err(got, ref)
+    if out.Cpad > Cout:
+        assert float(out.t[..., Cout:].float().abs().max()) == 0.0
+
+
 BOX_CASES = [
     # name, N, Cin, Cout, spatial(in), upsample   (2-D 3x3 s1 p1, W % 16 == 0, H % 32 != 0: the halo kernel declines,
     # the box-resident kernel takes them; TH = rows of 16 positions per workgroup follows from the grid size)
