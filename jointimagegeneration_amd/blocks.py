@@ -182,7 +182,11 @@ class Downsample(nn.Module):
 
     def run(self, h: CL) -> CL:
         pw, pb = packed_conv(self.op, h.Cpad)
-        return ops.conv(h, pw, pb, self.out_channels, k=_k3(self.op.weight), stride=2, pad=1)
+        # the output is a skip tensor: a decoder GroupNorm over cat[h, skip] takes its statistics from accumulators only if BOTH sources
+        # carry them, so leave the sums behind also below ops.GN_ACC_MIN_ELEMS (the 16x16 x 320 tensor of the latent UNet: otherwise
+        # that norm falls back to a statistics launch + an apply launch)
+        small = (h.S // (4 if self.dims == 2 else 8)) * pad32(self.out_channels) >= (1 << 16)
+        return ops.conv(h, pw, pb, self.out_channels, k=_k3(self.op.weight), stride=2, pad=1, want_stats=small)
 
 
 class ResBlock(TimestepBlock):
