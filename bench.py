@@ -92,6 +92,71 @@ def launch_ranks(args) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ roofline legs
+def measured_peaks(device):
+    """What THIS box delivers (SURVEY.md 8d last sentence): a register-resident bf16 MFMA loop on every CU (random
+    non-zero operands, ~0.3 s per shape after a warm-up launch, so the chip is at the clock it holds under matrix load) and a
+    16-bytes-per-lane stream copy of 1 GiB (read + write bytes).  HIP events on the launching stream; untimed part of the bench."""
+    import ctypes
+    import torch
+    from jointimagegeneration_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    sink = torch.zeros(4, device=device)
+    out = {}
+
+    def mfma(shape, wps, iters):
+        fl = ctypes.c_double(0.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.gg_ubench_mfma_bf16(shape, iters, wps, sink.data_ptr(), ctypes.byref(fl), stream), "gg_ubench_mfma_bf16")
+        e1.record()
+        torch.cuda.synchronize()
+        return fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, e0.elapsed_time(e1)
+
+    best = {}
+    for shape, name in ((0, "16x16x32"), (1, "32x32x16")):
+        for wps in (1, 2):
+            mfma(shape, wps, 20000)                                       # warm-up (code load, clock ramp)
+            tf, ms = mfma(shape, wps, 600000 // wps)                      # ~150-300 ms of back-to-back MFMAs per SIMD
+            if tf > best.get(name, (0, 0, 0))[0]:
+                best[name] = (tf, wps, ms)
+    out["mfma_tflops"] = round(max(v[0] for v in best.values()), 1)
+    out["mfma_by_shape"] = {k: {"tflops": round(v[0], 1), "waves_per_simd": v[1], "ms": round(v[2], 1)} for k, v in best.items()}
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    rates = []
+    for i in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.gg_ubench_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream), "gg_ubench_stream_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        if i:
+            rates.append(2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    out["hbm_gbs"] = round(max(rates), 1)
+    out["how"] = ("mfma: register-resident v_mfma bf16 loop on every SIMD (gg_ubench_mfma_bf16, random operands, best of 1 / 2 waves per SIMD "
+                  "and of the two shapes); hbm: 1 GiB float4 grid-stride copy (gg_ubench_stream_copy), read + write bytes, best of 5")
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
+def add_measured_fractions(roofline, peaks):
+    """frac_vs_measured beside every frac: the same achieved figure over the box's own MFMA / copy rate instead of the vendor peak."""
+    def one(e):
+        if not isinstance(e, dict) or "achieved" not in e or "unit" not in e:
+            return
+        peak = peaks["mfma_tflops"] if e["unit"] == "TFLOP/s" else peaks["hbm_gbs"]
+        e["frac_vs_measured"] = round(e["achieved"] / peak, 4)
+    one(roofline)
+    for e in roofline.get("stages", {}).values():
+        one(e)
+    if isinstance(roofline.get("all_3x3x3_convs"), dict) and "achieved" in roofline["all_3x3x3_convs"]:
+        roofline["all_3x3x3_convs"]["frac_vs_measured"] = round(roofline["all_3x3x3_convs"]["achieved"] / peaks["mfma_tflops"], 4)
+    roofline["measured_peak"] = peaks
+
+
 def conv_roofline(pipe, device):
     """Judged kernel = the 3-D halo-tile implicit-GEMM conv (`conv_halo_kernel<1,NT,UP>`) of the CCDM UNet
     (3x3x3 convs are 99.3 % of the UNet's FLOPs; the halo kernel runs all of them at the 128^3..32^3 levels).
@@ -397,6 +462,11 @@ def main():
         if not args.no_roofline:
             log("roofline legs (HIP events)")
             line_extra["roofline"] = conv_roofline(pipe, device)
+            log("measured peaks (MFMA microbenchmark, stream copy)")
+            try:
+                line_extra["measured_peak"] = measured_peaks(device)
+            except Exception as e:                                           # never lose the line to an auxiliary leg
+                line_extra["measured_peak"] = {"error": repr(e)}
         # single-GPU characterisation legs (~50 s): only at N = 1, so that in a multi-rank run no rank waits for rank 0 in a barrier
         if not args.no_roofline and not args.no_extra and world == 1:
             log("roofline legs of the configurations off the C5 wall (SpatialTransformer UNet, pixel-space UNet)")
@@ -486,6 +556,12 @@ def main():
                     line["roofline"]["wall_shares"], line["roofline"]["dominant_by_wall"] = wall_shares(st, elapsed / done * 1e3, args.ccdm_steps, args.slices)
                 except Exception as e:                                       # never lose the line to an auxiliary leg
                     line["roofline"]["stages_error"] = repr(e)
+            peaks = line.pop("measured_peak", None)
+            if "roofline" in line and peaks is not None:
+                if "error" in peaks:
+                    line["roofline"]["measured_peak"] = peaks
+                else:
+                    add_measured_fractions(line["roofline"], peaks)
         line["wall_s_total"] = round(time.time() - T_START, 1)
         print(json.dumps(line), flush=True)
     ggd.finalize()

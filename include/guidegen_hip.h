@@ -309,6 +309,18 @@ int gg_groupnorm_f32(const float *src1, int32_t C1, const float *src2, int32_t C
 /* gg_attention_desc with fp32 q / k / v / out (head_dim <= 64): softmax((q a)(k a)^T) v, a = sqrt(scale), all fp32. */
 int gg_attention_forward_f32(const gg_attention_desc *desc, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-box peak measurements for the benchmark's roofline (gg_ubench.hip; SURVEY.md 8d, BASELINE.md 3: fractions are quoted against
+ * the vendor peaks AND against what this box delivers).  Measurement infrastructure: nothing on the sampling path calls them.
+ * No counterpart in the reference (it publishes no numbers: README.md:1-41).
+ * ------------------------------------------------------------------------------------------------ */
+/* Register-resident bf16 MFMA loop on every CU: cus * waves_per_simd workgroups of 256 threads, `iters` iterations of 262 144 FLOP
+ * per wave (shape 0: 16 x v_mfma_f32_16x16x32_bf16, shape 1: 8 x v_mfma_f32_32x32x16_bf16), random non-zero operands.  The caller
+ * times the launch with events on `stream`; *flops_out (host) receives the FLOP count of the launch.  sink: >= 1 float (device). */
+int gg_ubench_mfma_bf16(int32_t shape, int32_t iters, int32_t waves_per_simd, float *sink, double *flops_out, void *stream);
+/* 16 bytes per lane grid-stride copy src -> dst (device pointers, 16-byte aligned, bytes % 16 == 0): moves 2 * bytes through HBM. */
+int gg_ubench_stream_copy(const void *src, void *dst, int64_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,8 @@ SIGNATURES = {
     "gg_groupnorm_f32": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, i32, vp, vp, vp]),
     "gg_attention_forward_f32": (C.c_int, [C.POINTER(AttentionDesc), vp]),
     "gg_mask_to_cond_slice": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "gg_ubench_mfma_bf16": (C.c_int, [i32, i32, i32, vp, C.POINTER(C.c_double), vp]),
+    "gg_ubench_stream_copy": (C.c_int, [vp, vp, i64, vp]),
 }
 
 _lib = None

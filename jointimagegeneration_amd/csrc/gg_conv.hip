@@ -838,7 +838,13 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
             default: return launch_gather<1>(p, stream);
         }
     }
+#ifdef GG_H3_STAMPS
+    if (d->path_hint == 7 && d->workspace) p.ws = (float *)d->workspace;      // diagnostic build: phase stamps of the team halo kernel
+#endif
     int rc = gg_conv_halo_try(p, stream);
+#ifdef GG_H3_STAMPS
+    p.ws = nullptr;
+#endif
     if (rc != GG_ERR_UNSUPPORTED) return rc;
 #ifdef GG_BOX_STAMPS
     if (d->path_hint == 98) p.ws = (float *)d->workspace;      // diagnostic build: phase stamps of the box kernel

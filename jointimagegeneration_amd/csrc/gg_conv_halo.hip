@@ -363,6 +363,9 @@ static int dispatch_nt(const ConvParams &p, int NT, hipStream_t stream)
     }
 }
 
+// team kernel for filled 3-D grids (gg_conv_halo3.hip); same contract
+int gg_conv_halo3_try(const ConvParams &p, hipStream_t stream);
+
 // Returns GG_ERR_UNSUPPORTED (silently, no error text) when the shape is outside the envelope: the caller then uses the
 // generic gather kernel.  stream == (hipStream_t)-1: dry run (only answers whether the halo kernel would be used).
 int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
@@ -371,6 +374,15 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (!(p.kh == 3 && p.kw == 3 && (p.kd == 3 || p.kd == 1))) return GG_ERR_UNSUPPORTED;
     if (p.stride != 1 || p.pad != 1) return GG_ERR_UNSUPPORTED;
     if (!d3 && p.D != 1) return GG_ERR_UNSUPPORTED;
+    // path_hint 7 (tests, A/B probes): the team kernel wherever its envelope allows; 8: production dispatch WITHOUT the team kernel.
+    // GG_HALO3_DEFAULT decides what production (path_hint 0) does.
+#ifndef GG_HALO3_DEFAULT
+#define GG_HALO3_DEFAULT 0
+#endif
+    if (d3 && ((GG_HALO3_DEFAULT && p.path_hint == 0) || p.path_hint == 7)) {
+        const int rc3 = gg_conv_halo3_try(p, stream);
+        if (rc3 != GG_ERR_UNSUPPORTED) return rc3;
+    }
     const int TD = d3 ? 4 : 1, TH = d3 ? 8 : 32, TW = 16;
     if (p.Wo % TW || p.Ho % TH || p.Do % TD) return GG_ERR_UNSUPPORTED;
     const int G = p.Cout_pad / 32;
@@ -392,7 +404,7 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     // under-filled grids: the box / split-K gather paths are faster (2-D under one workgroup per CU: AE 512->512 @64x64 is 136 us
     // here at 128 workgroups); path_hint 1 / 4 / 6 (tests) lift the gate so that small shapes run on this kernel
     const long long min_blocks = (d3 || (wide2d && NT > 1)) ? 128 : 256;
-    if (p.path_hint != 1 && p.path_hint != 4 && p.path_hint != 6 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
+    if (p.path_hint != 1 && p.path_hint != 4 && p.path_hint != 6 && p.path_hint != 7 && blocks < min_blocks) return GG_ERR_UNSUPPORTED;
     if (stream == (hipStream_t)-1) return GG_OK;
     // 3-D grids of at most one 512-position workgroup per CU: 256-position boxes (HB: 4x4x16, three workgroups per CU) double the
     // grid; same-box A/B 256->256 @32^3: 141 vs 156 us.  On filled grids the two box sizes are within +-3 % (64->64 @128^3
@@ -402,11 +414,11 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     // the halo redundancy drops from 2.1x to 1.76x, i.e. less staging (loads, GroupNorm*SiLU, LDS writes) per output.  Same-box A/B at
     // 128^3 with the fused prologue: 64->64 500 -> 468 us, 192->64 1338 -> 1240 us, 32->64 300 -> 280 us (bit-identical results);
     // 256->256 @32^3 would lose (177 vs 156 us: half the workgroups), hence the grid condition.  path_hint 6 (tests) forces it.
-    if (d3 && NT <= 2 && !p.upsample && (p.Do % 8) == 0 && (p.path_hint == 6 || (p.path_hint == 0 && blocks >= 512))) {
+    if (d3 && NT <= 2 && !p.upsample && (p.Do % 8) == 0 && (p.path_hint == 6 || ((p.path_hint == 0 || p.path_hint == 8) && blocks >= 512))) {
         if (NT == 2) return launch_halo<1, 2, 0, 2>(p, stream);
         return launch_halo<1, 1, 0, 2>(p, stream);
     }
-    if (d3 && NT <= 2 && (p.path_hint == 4 || (p.path_hint == 0 && blocks <= 256))) {
+    if (d3 && NT <= 2 && (p.path_hint == 4 || ((p.path_hint == 0 || p.path_hint == 8) && blocks <= 256))) {
         if (NT == 2) return p.upsample ? launch_halo<1, 2, 1, 1>(p, stream) : launch_halo<1, 2, 0, 1>(p, stream);
         return p.upsample ? launch_halo<1, 1, 1, 1>(p, stream) : launch_halo<1, 1, 0, 1>(p, stream);
     }
