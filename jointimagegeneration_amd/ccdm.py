@@ -180,6 +180,10 @@ class DenoisingModel(nn.Module):
             if not bf16_in:                                           # fp32 validation mode: the one-hot input is refreshed by an index scatter
                 ops.labels_to_onehot(lab, K, xin.view(M, -1))
 
+        if rng_tapes is not None:
+            need = sum(1 for t in tv if t > 1)                        # one exponential tape per DRAWING step (t = 1 takes the argmax)
+            if len(rng_tapes) < need:
+                raise ValueError(f"sample_labels: {need} drawing steps (t = {tv[0]} .. 2) need {need} rng tapes, got {len(rng_tapes)}")
         use_graph = self.use_graph and rng_tapes is None and trace is None and S > 3 and not ops.FP32
         graph, warmed, ti = None, False, 0
         for i, t in enumerate(tv):

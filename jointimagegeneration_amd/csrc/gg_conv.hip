@@ -740,6 +740,8 @@ bool gg_conv_box_prologue_from_acc(const ConvParams &p);
 extern "C" int gg_conv_prologue_from_acc(const gg_conv_desc *d)
 {
     if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu || !d->prologue_act) return 0;
+    // two sources: the fold takes channel c < C1 from pro_acc1 and c - C1 from pro_acc2, i.e. every channel of the FIRST source must be a
+    // logical one (pro_c_logical >= C1 says exactly that: padding lanes may only sit at the end of the second source)
     if (d->pro_c_logical <= 0 || d->pro_c_logical % 32 || d->pro_c_logical > d->C1 + d->C2 || (d->C2 && d->pro_c_logical < d->C1)) return 0;
     ConvParams p;
     fill_params(d, p);

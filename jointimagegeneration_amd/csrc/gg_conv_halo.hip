@@ -265,37 +265,103 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
     for (int a = 0; a < 2 * NT; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
+    // gfx950 counts loads and stores in ONE in-order counter (vmcnt): a load issued behind a store cannot be waited for without waiting
+    // for the store's whole round trip.  With the bias / residual load of every tile behind the previous tile's store, the epilogue of
+    // a 1024-position box took ~23 k cycles (half a chunk's taps; in-kernel stamps of the same pattern in gg_conv_halo3.hip: 25 k cycles
+    // for 32 tiles).  So: the bias vectors and ALL residual pieces are loaded in front of the first store.
+    if constexpr (!GG_HALO_W16(D3, NT, HB)) {
+        f32x4 bvec[2 * NT];
 #pragma unroll
-    for (int tt = 0; tt < TPW; ++tt) {
-        const int tile = wave * TPW + tt;
-        const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
-        const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
+        for (int ct = 0; ct < 2 * NT; ++ct) bvec[ct] = brow ? *reinterpret_cast<const f32x4 *>(brow + g0 * 32 + ct * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        auto out_off = [&](int tt) -> long long {
+            const int tile = wave * TPW + tt;
+            const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+            const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
+            return m * p.Cout_pad + g0 * 32 + fq * 4;
+        };
+        // all residual pieces of the wave's tiles in flight at once (TPW x 2 NT x 2 registers: 64 where the wave owns 128 positions x 64
+        // couts; the operand fragments are dead by now): ONE memory round trip in front of the stores instead of one per tile row
+        // (NT >= 3: 64 statistics + 32 bias registers beside the 128 accumulators leave no room for that; there the pieces of tile row
+        // tt + 1 are requested before the stores of row tt, so that the wait for them skips those stores)
+        constexpr bool ALLRES = NT <= 2;
+        constexpr int RD = ALLRES ? TPW : 2;
+        bf16x4 rres[RD][2 * NT];
+        auto prefetch = [&](int tt) {
+            const long long o1 = out_off(tt);
 #pragma unroll
-        for (int ct = 0; ct < 2 * NT; ++ct) {
-            const int co = g0 * 32 + ct * 16 + fq * 4;
-            f32x4 v = acc[tt][ct];
-            if (brow) v += *reinterpret_cast<const f32x4 *>(brow + co);
-            const long long o = m * p.Cout_pad + co;
-            if (p.residual) {
-                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+            for (int ct = 0; ct < 2 * NT; ++ct) rres[tt % RD][ct] = *reinterpret_cast<const bf16x4 *>(p.residual + o1 + ct * 16);
+        };
+        if (p.residual) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-            }
+            for (int tt = 0; tt < (ALLRES ? TPW : 1); ++tt) prefetch(tt);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (co + j >= p.Cout) v[j] = 0.f;
-            if (p.out_dtype == GG_F32) {
-                *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
-            } else {
-                bf16x4 ob;
+        for (int tt = 0; tt < TPW; ++tt) {
+            const long long ob = out_off(tt);
+            if (!ALLRES && p.residual && tt + 1 < TPW) prefetch(tt + 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ob[j] = (bf16_t)v[j];
-                    const float f = (float)ob[j];               // what the next norm will read
-                    ssum[ct][j] += f;
-                    ssq[ct][j] += f * f;
+            for (int ct = 0; ct < 2 * NT; ++ct) {
+                const int co = g0 * 32 + ct * 16 + fq * 4;
+                f32x4 v = acc[tt][ct];
+                if (brow) v += bvec[ct];
+                const long long o = ob + ct * 16;
+                if (p.residual) {
+                    const bf16x4 r = rres[tt % RD][ct];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                 }
-                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co + j >= p.Cout) v[j] = 0.f;
+                if (p.out_dtype == GG_F32) {
+                    *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+                } else {
+                    bf16x4 ob4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ob4[j] = (bf16_t)v[j];
+                        const float f = (float)ob4[j];               // what the next norm will read
+                        ssum[ct][j] += f;
+                        ssq[ct][j] += f * f;
+                    }
+                    *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob4;
+                }
+            }
+        }
+    } else {
+        // (16 waves at a 128-register budget: two tile rows per wave, no room for a hoisted bias vector set; the loop is two rows short anyway)
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int tile = wave * TPW + tt;
+            const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+            const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
+#pragma unroll
+            for (int ct = 0; ct < 2 * NT; ++ct) {
+                const int co = g0 * 32 + ct * 16 + fq * 4;
+                f32x4 v = acc[tt][ct];
+                if (brow) v += *reinterpret_cast<const f32x4 *>(brow + co);
+                const long long o = m * p.Cout_pad + co;
+                if (p.residual) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co + j >= p.Cout) v[j] = 0.f;
+                if (p.out_dtype == GG_F32) {
+                    *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+                } else {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ob[j] = (bf16_t)v[j];
+                        const float f = (float)ob[j];               // what the next norm will read
+                        ssum[ct][j] += f;
+                        ssq[ct][j] += f * f;
+                    }
+                    *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
+                }
             }
         }
     }

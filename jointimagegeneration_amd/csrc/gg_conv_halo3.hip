@@ -148,15 +148,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_team_kernel(const ConvParam
                 // two-stage software pipeline over the rounds (compile-time indices): the LDS reads of round r + 1 are in flight while round r
                 // is computed, and no branch stands between them: a lone pair of waves per SIMD has nothing else to hide the LDS latency with
                 struct Piece { bf16x8 x; f32x4 s0, s1, b0, b1; int keep; };
-                Piece pc2[2];
-                auto load = [&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    Piece &q = pc2[r & 1];
+                Piece pa, pb;
+                auto load = [&](Piece &q, const int r) {
                     const int id = id0 + chd, ih = ih0 + chh, iw = iw0 + chw;
                     const int o = (int)((unsigned)id < (unsigned)pD) & (int)((unsigned)ih < (unsigned)pH) & (int)((unsigned)iw < (unsigned)pW);
                     q.keep = -o;                            // all ones inside the tensor, zero in the padding
                     const int gq = slot ^ fsw(chw);
-                    const int row = rowb + 128 * r < H3_NROWS ? rowb + 128 * r : rowb;       // (only the upper lanes of the last piece: they rewrite round 0's row unchanged below)
+                    const int row = rowb + 128 * r < H3_NROWS ? rowb + 128 * r : rowb;       // (beyond the box: a harmless re-read, never written back)
                     q.x = *reinterpret_cast<const bf16x8 *>(bx + row * 64 + slot * 16);
                     if constexpr (PRO != 0) {
                         q.s0 = *reinterpret_cast<const f32x4 *>(ssb + gq * 8); q.s1 = *reinterpret_cast<const f32x4 *>(ssb + gq * 8 + 4);
@@ -166,10 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_team_kernel(const ConvParam
                     if (chw >= H3_HW) { chw -= H3_HW; chh += 1; }
                     if (chh >= H3_HH) { chh -= H3_HH; chd += 1; }
                 };
-                auto work = [&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    const Piece &q = pc2[r & 1];
-                    const bool inbox = rowb + 128 * r < H3_NROWS;
+                auto work = [&](const Piece &q, const int r, const bool guard) {
                     u32x4 t = __builtin_bit_cast(u32x4, q.x);
                     if constexpr (PRO != 0) {
                         bf16x8 yb;
@@ -187,23 +182,19 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_team_kernel(const ConvParam
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[e] &= (unsigned)q.keep;                   // zero padding stays zero
-                    if (r < 8 || inbox) *reinterpret_cast<u32x4 *>(bx + (rowb + 128 * r) * 64 + slot * 16) = t;
+                    if (!guard || rowb + 128 * r < H3_NROWS) *reinterpret_cast<u32x4 *>(bx + (rowb + 128 * r) * 64 + slot * 16) = t;
                 };
-                using std::integral_constant;
-                load(integral_constant<int, 0>{});
-                load(integral_constant<int, 1>{}); work(integral_constant<int, 0>{});
-                load(integral_constant<int, 2>{}); work(integral_constant<int, 1>{});
-                load(integral_constant<int, 3>{}); work(integral_constant<int, 2>{});
-                load(integral_constant<int, 4>{}); work(integral_constant<int, 3>{});
-                load(integral_constant<int, 5>{}); work(integral_constant<int, 4>{});
-                load(integral_constant<int, 6>{}); work(integral_constant<int, 5>{});
-                load(integral_constant<int, 7>{}); work(integral_constant<int, 6>{});
-                if (wave < 4) {                             // pieces 64 .. 67 (the last one covers 8 rows only)
-                    load(integral_constant<int, 8>{}); work(integral_constant<int, 7>{});
-                    work(integral_constant<int, 8>{});
-                } else {
-                    work(integral_constant<int, 7>{});
+                // a ROLLED loop of two rounds per iteration: 1.5 KB of code that stays in the instruction cache, instead of 7 KB of cold
+                // straight-line code per call site
+                load(pa, 0);
+#pragma unroll 1
+                for (int r = 0; r < 8; r += 2) {
+                    load(pb, r + 1);
+                    work(pa, r, false);
+                    load(pa, r + 2);
+                    work(pb, r + 1, false);
                 }
+                if (wave < 4) work(pa, 8, true);            // pieces 64 .. 67 (the last one covers 8 rows only)
             }
         }
 #ifdef GG_H3_STAMPS

@@ -98,7 +98,10 @@ def main(argv=None):
             feats = torch.randn((1, fce.embed_dim, int(params.get("context_length", 512))), generator=torch.Generator(device=dev).manual_seed(7), device=dev)
             context = fce(feats)        # computed as evaluator.py:166-169 does; the shipped UNet takes no context and ignores it
             print(f"[rank {rank}] feature_cond_encoder context {tuple(context.shape)} (not consumed by the shipped UNet)", file=sys.stderr)
-        except Exception as e:          # the eval itself does not need the encoder: a mismatching encoder checkpoint must not abort it
+        except RuntimeError as e:       # load_state_dict mismatch (the reference's load would raise, ccdm/ddpm/trainer.py:444-463)
+            if getattr(model.unet, "context_dim", None) is not None:
+                raise                   # a UNet that consumes the context must not silently run unconditioned
+            # the shipped UNet takes no context: the eval does not need the encoder, say so and go on
             print(f"[rank {rank}] WARNING: feature_cond_encoder skipped ({type(e).__name__}: {e})", file=sys.stderr)
     out_dir = args.out or os.path.join(params.get("output_path", "."), args.exp_name)
     os.makedirs(out_dir, exist_ok=True)

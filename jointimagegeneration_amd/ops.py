@@ -203,6 +203,8 @@ def conv_prologue_from_acc(src1: CL, cout: int, act: bool, k=(1, 3, 3), stride: 
     layout): no statistics, scale / shift or apply launch at all (gg_conv_desc.pro_acc1)."""
     if not PROLOGUE_FROM_ACC or is_f32(src1.t) or not has_stats(src1, src2):
         return False
+    if src2 is not None and src1.C != src1.Cpad:        # the in-kernel fold indexes channel c - C1 of the second source: C1 must be all logical
+        return False
     lib = _lib.load()
     N, D, H, W, C1 = src1.t.shape
     Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
@@ -275,10 +277,12 @@ _ARENAS = {}
 
 
 def stats_begin(device) -> None:
-    """Start of a network forward: zero the arena and rewind.  Zeroed is the prefix any forward so far has used (the high-water mark,
-    rounded up to 64 Ki entries; entries beyond it have never been written: they are still the zeros of the allocation), so a captured
-    hipGraph stays correct whatever other network dirtied the arena between its replays, and the fill (a dependent launch at the head
-    of every forward, and 4 MiB of dirty L2 lines when the whole arena was zeroed) covers only what is in use (~1 MiB for the latent UNet)."""
+    """Start of a network forward: zero the arena and rewind.  Eager: zeroed is the prefix any forward so far has used (the high-water
+    mark, rounded up to 64 Ki entries; entries beyond it have never been written: they are still the zeros of the allocation), so the
+    fill (a dependent launch at the head of every forward, and 4 MiB of dirty L2 lines when the whole arena was zeroed) covers only what
+    is in use (~1 MiB for the latent UNet).  While a hipGraph is being CAPTURED the whole arena is zeroed instead: the captured memset is
+    fixed at capture time, and a forward captured cold (no eager run before it, so the mark still is 0) or one that allocates past the
+    mark would otherwise replay onto its own previous sums."""
     if not GN_ACC:
         return
     a = _ARENAS.get(str(device))
@@ -286,8 +290,11 @@ def stats_begin(device) -> None:
         a = _ARENAS[str(device)] = dict(buf=torch.zeros(_ARENA_ENTRIES, dtype=torch.int64, device=device), off=0, hi=0, active=False)
     else:
         a["hi"] = max(a["hi"], a["off"])
-        if a["hi"]:
-            a["buf"][:min(_ARENA_ENTRIES, (a["hi"] + 65535) // 65536 * 65536)].zero_()
+    if torch.cuda.is_current_stream_capturing():
+        a["buf"].zero_()
+        a["hi"] = _ARENA_ENTRIES                    # every later eager forward zeroes everything a replay may have dirtied
+    elif a["hi"]:
+        a["buf"][:min(_ARENA_ENTRIES, (a["hi"] + 65535) // 65536 * 65536)].zero_()
     a["off"] = 0
     a["active"] = True
 

@@ -147,8 +147,11 @@ class CCDMUNetModel(_UNetBase):
                  disabled_sa=False, use_linear_in_transformer=False):
         super().__init__()
         if use_scale_shift_norm or resblock_updown or use_new_attention_order or ce_head or num_classes is not None \
-                or use_spatial_transformer or use_fp16:
+                or use_spatial_transformer:
             raise NotImplementedError("option outside the shipped CCDM configuration (params_eval.yml:58-64)")
+        # use_fp16 (unet.py:447,742-756: the reference casts the torso to half precision) is ACCEPTED and has no effect: this engine's
+        # torso always runs on bf16 tensors with fp32 accumulation (ops.fp32_validation() is the switch to full precision)
+        self.use_fp16 = bool(use_fp16)
         if feature_cond_encoder is not None and feature_cond_encoder.get("type", "none") not in ("none", None):
             raise NotImplementedError("feature_cond_encoder is 'none' in the shipped config; DINO/ResNet features are out of scope")
         if num_heads_upsample == -1:

@@ -8,6 +8,7 @@ kernel is fed the same fp32 probabilities as the oracle.
 """
 import json
 import math
+import zlib
 
 import numpy as np
 import pytest
@@ -59,7 +60,7 @@ CONV_CASES = [
 def test_conv_matches_oracle(dev, case):
     from jointimagegeneration_amd import ops
     name, dims, N, Cin, Cout, sp, k, stride, pad, up = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn((N, Cin) + sp, generator=g)
     w = torch.randn((Cout, Cin) + (k,) * dims, generator=g) / math.sqrt(Cin * k ** dims)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -101,7 +102,7 @@ def test_conv_halo_kernel_matches_oracle(dev, case, halo_hint):
     name, dims, N, Cin, Cout, sp, up = case
     assert ops.conv_fuses_prologue(ops.CL(torch.empty((N,) + (1,) * (3 - dims) + sp + (ops.pad32(Cin),), dtype=torch.bfloat16, device=dev), Cin),
                                    Cout, k=(1,) * (3 - dims) + (3,) * dims, upsample=up)        # really the halo kernel
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn((N, Cin) + sp, generator=g)
     w = torch.randn((Cout, Cin) + (3,) * dims, generator=g) / math.sqrt(Cin * 3 ** dims)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -268,7 +269,7 @@ BOX_CASES = [
 def test_conv_box_kernel_matches_oracle(dev, case):
     from jointimagegeneration_amd import ops
     name, N, Cin, Cout, sp, up = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn((N, Cin) + sp, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
     b = torch.randn(Cout, generator=g) * 0.1
@@ -1227,3 +1228,49 @@ def test_invalidate_caches_after_data_writes(dev):
     ops.invalidate_caches(u)
     y1 = u(x, t)
     assert float((y1 - 2.0 * y0).abs().max()) <= 2e-2 * float(y1.abs().max())      # head conv is linear in its weights
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # N, C1, C2, Cout, spatial, prologue, silu, residual, per-sample bias
+    (1, 64, 0, 64, (8, 8, 16), False, True, False, False),          # one item, two chunks, no prologue
+    (2, 64, 32, 128, (8, 16, 32), True, False, True, True),         # two sources, two cout groups, N = 2, affine-only prologue, residual
+    (1, 128, 64, 64, (24, 8, 48), True, True, False, True),         # six chunks, odd tile counts, GroupNorm * SiLU prologue
+    (1, 96, 0, 192, (32, 64, 64), True, True, True, False),         # 384 items on 256 workgroups: ragged persistent loop
+], ids=["one_item", "two_sources_n2", "six_chunks", "ragged_persistent"])
+def test_team_halo_conv_bit_identical_to_halo_kernel(dev, case):
+    """The team kernel (gg_conv_halo3.hip, path_hint 7: hand-scheduled tap phase, LDS-DMA staging, antiphase teams) against
+    conv_halo_kernel (path_hint 1) on the same inputs: same MFMA, same tap / chunk order per accumulator, same epilogue arithmetic =>
+    bit-identical outputs; the GroupNorm sums it leaves are the same exact integers where both kernels tile a wave alike, equal to
+    fp32 rounding of the partial sums otherwise."""
+    from jointimagegeneration_amd import ops
+    N, C1, C2, Cout, sp, pro, silu, res, per_sample = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000)
+    x1 = ops.CL(torch.randn((N,) + sp + (C1,), generator=g).to(dev).bfloat16(), C1)
+    x2 = ops.CL(torch.randn((N,) + sp + (C2,), generator=g).to(dev).bfloat16(), C2) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, 3, generator=g).to(dev) / math.sqrt((C1 + C2) * 27)
+    pw = ops.pack_conv_weight(w, C1 + C2)
+    cp = ops.pad32(Cout)
+    if per_sample:
+        bias = torch.zeros(N, cp, device=dev); bias[:, :Cout] = torch.randn(N, Cout, generator=g).to(dev)
+    else:
+        bias = ops.pad_bias(torch.randn(Cout, generator=g).to(dev), Cout, dev)
+    r = ops.CL(torch.randn((N,) + sp + (cp,), generator=g).to(dev).bfloat16(), Cout) if res else None
+    prol = None
+    if pro:
+        gamma, beta = (1 + 0.1 * torch.randn(C1 + C2, generator=g)).to(dev), (0.1 * torch.randn(C1 + C2, generator=g)).to(dev)
+        prol = ops.groupnorm_stats(x1, gamma, beta, 1e-5, src2=x2)
+    outs, sums = {}, {}
+    old = ops.PATH_HINT
+    try:
+        for hint in (1, 7):
+            ops.PATH_HINT = hint
+            ops.stats_begin(dev)
+            y = ops.conv(x1, pw, bias, Cout, k=(3, 3, 3), src2=x2, residual=r, bias_per_sample=per_sample, prologue=prol, prologue_silu=silu)
+            sums[hint] = y.acc.sum(1).clone()
+            ops.stats_end(dev)
+            outs[hint] = y.t.clone()
+    finally:
+        ops.PATH_HINT = old
+    assert torch.equal(outs[1], outs[7])
+    assert float((sums[1] - sums[7]).abs().max()) <= 2e-6 * float(sums[1].abs().max())
