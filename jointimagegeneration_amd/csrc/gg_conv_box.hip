@@ -744,14 +744,21 @@ __global__ __launch_bounds__(GG_BOX_NW * 64) void conv_box2d_kernel(const ConvPa
         for (int j = 0; j < 4; ++j)
             if (co_thr + j >= p.Cout) a[j] = 0.f;
         if (p.out_dtype == GG_F32) {
+            // (the DDIM state and scalars are requested BEFORE the eps store: loads and stores share one in-order counter on gfx950, a
+            //  load behind the store would wait for the store's round trip)
+            const bool dd = p.ddim_x && co_thr == 0;
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, dsc = f32x4{1.f, 1.f, 0.f, 0.f};
+            if (dd) {
+                xv = *reinterpret_cast<const f32x4 *>(p.ddim_x + mo * 4);
+                dsc = *reinterpret_cast<const f32x4 *>(p.ddim_scalars);
+            }
             *reinterpret_cast<f32x4 *>((float *)p.out + o) = a;
-            if (p.ddim_x && co_thr == 0) {
+            if (dd) {
                 // fused DDIM update (ddim.py:190-204), the UNet head conv's eps still in registers; same fp32 expression order as
                 // ddim_step_kernel (bit-identical results)
 #pragma clang fp contract(off)
-                const float a_t = p.ddim_scalars[0], a_prev = p.ddim_scalars[1], sigma = p.ddim_scalars[2], s1m = p.ddim_scalars[3];
+                const float a_t = dsc[0], a_prev = dsc[1], sigma = dsc[2], s1m = dsc[3];
                 const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dirc = sqrtf(1.0f - a_prev - sigma * sigma);
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(p.ddim_x + mo * 4);
                 f32x4 px0, xn;
                 bf16x4 xb;
 #pragma unroll

@@ -450,10 +450,15 @@ class LatentDiffusion(nn.Module):
 
 # ================================================================================================ DDIM
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
-    if ddim_discr_method != "uniform":
-        raise NotImplementedError(ddim_discr_method)
-    c = num_ddpm_timesteps // num_ddim_timesteps
-    return np.asarray(list(range(0, num_ddpm_timesteps, c))) + 1
+    """ldm/modules/diffusionmodules/util.py:46-59 (both discretisations; + 1 "to get the final alpha values right")."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ddim_timesteps + 1
 
 
 class DDIMSampler(object):
@@ -503,26 +508,25 @@ class DDIMSampler(object):
     def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
                quantize_x0=False, eta=0.0, mask=None, x0=None, temperature=1.0, noise_dropout=0.0, score_corrector=None,
                corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.0,
-               unconditional_conditioning=None, noise_tape: Optional[Sequence[torch.Tensor]] = None, **kwargs):
-        if mask is not None or score_corrector is not None or quantize_x0 or unconditional_guidance_scale != 1.0 \
-                or noise_dropout > 0.0 or temperature != 1.0:
-            raise NotImplementedError("inpainting / guidance / correctors are not on the scoped path (sample_diffusion.py:212-220)")
-        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
+               unconditional_conditioning=None, noise_tape: Optional[Sequence[torch.Tensor]] = None, ddim_discretize="uniform", **kwargs):
+        """`ddim_discretize` ("uniform" | "quad": make_schedule's argument, ddim.py:24) is this package's addition to the signature: the
+        reference's sample() always builds the uniform schedule and reaches "quad" only through make_schedule + ddim_sampling.
+        Classifier-free guidance (ddim.py:175-180) runs as two UNet evaluations per step and one linear combination."""
+        if mask is not None or score_corrector is not None or quantize_x0 or noise_dropout > 0.0 or temperature != 1.0:
+            raise NotImplementedError("inpainting / correctors / quantisation are not on the scoped path (sample_diffusion.py:212-220)")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=ddim_discretize, ddim_eta=eta, verbose=False)
         size = (batch_size,) + tuple(shape)
         dev = self.model.device
         img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev).float()
-        z, pred_x0 = self._sample_cl(img, conditioning, eta, noise_tape)
+        cfg = None
+        if unconditional_conditioning is not None and unconditional_guidance_scale != 1.0:
+            cfg = (unconditional_conditioning, float(unconditional_guidance_scale))
+        z, pred_x0 = self._sample_cl(img, conditioning, eta, noise_tape, cfg)
         return z, {"x_inter": [img, z], "pred_x0": [img, pred_x0]}
 
     # ---- channels-last fast path -------------------------------------------------------------------------
-    def _sample_cl(self, x_T: torch.Tensor, conditioning, eta: float, noise_tape):
-        model = self.model
-        unet = model.model.diffusion_model
-        ck = model.model.conditioning_key
-        dev = x_T.device
-        N, Cx = x_T.shape[:2]
-        sp = tuple(x_T.shape[2:])
-        nd = len(sp)
+    def _split_cond(self, conditioning):
+        ck = self.model.model.conditioning_key
         c_concat, context = None, None
         if conditioning is not None:
             if isinstance(conditioning, dict):
@@ -533,10 +537,24 @@ class DDIMSampler(object):
                 c_concat = conditioning
             elif ck == "crossattn":
                 context = conditioning
+        return c_concat, context
+
+    def _sample_cl(self, x_T: torch.Tensor, conditioning, eta: float, noise_tape, cfg=None):
+        model = self.model
+        unet = model.model.diffusion_model
+        ck = model.model.conditioning_key
+        dev = x_T.device
+        N, Cx = x_T.shape[:2]
+        sp = tuple(x_T.shape[2:])
+        nd = len(sp)
+        c_concat, context = self._split_cond(conditioning)
         st = self.prepare_state(N, Cx, sp, dev, c_concat.shape[1] if c_concat is not None else 0,
                                 ctx_shape=tuple(context.shape[1:]) if context is not None else None)
         self.load_state(st, x_T, c_concat, context)
-        self.run_steps(st, st["ctx"], eta, noise_tape)
+        if cfg is not None:
+            self._run_steps_cfg(st, x_T, cfg, eta, noise_tape)
+        else:
+            self.run_steps(st, st["ctx"], eta, noise_tape)
         perm = (0, nd + 1) + tuple(range(1, nd + 1))
         z = st["x"].view((N,) + sp + (Cx,)).permute(perm).contiguous()
         p0 = st["pred_x0"].view((N,) + sp + (Cx,)).permute(perm).contiguous()
@@ -592,6 +610,41 @@ class DDIMSampler(object):
         if not head.fused_ddim:
             ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), scal, noise=noise,
                           pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
+
+    def _run_steps_cfg(self, st, x_T, cfg, eta, noise_tape):
+        """Classifier-free guidance (ddim.py:175-180): e = e_u + s (e_c - e_u).  The reference stacks [uncond, cond] into one batch of 2 N;
+        every layer of the UNet is per sample, so two evaluations on the same x with the two conditionings give the same two halves.
+        Eager (off the timed path); the update kernel refreshes the conditional UNet input, the unconditional one copies x from it."""
+        unet = self.model.model.diffusion_model
+        uc_concat, uc_ctx = self._split_cond(cfg[0])
+        scale = cfg[1]
+        Cx, Cc = st["Cx"], st["Cc"]
+        M = st["x"].numel() // Cx
+        uin_u = st["unet_in"].clone()
+        if uc_concat is not None:
+            ops.to_cl(uc_concat.float(), out=uin_u, c_offset=Cx, zero_fill=False)
+        ctx_u = None
+        if uc_ctx is not None:
+            ctx_u = CL(torch.zeros_like(st["ctx"].t), st["ctx"].C)
+            ops.to_cl(uc_ctx.permute(0, 2, 1).contiguous().float(), out=ctx_u.t, c_offset=0, zero_fill=False)
+        elif st["ctx"] is not None:
+            ctx_u = st["ctx"]
+        eps_u = torch.empty_like(st["eps"])
+        for i in range(st["S"]):
+            noise = None
+            if noise_tape is not None:
+                nt = noise_tape[i].to(st["x"].device).float()
+                nd = nt.ndim - 2
+                noise = nt.permute((0,) + tuple(range(2, nd + 2)) + (1,)).contiguous()
+            elif eta != 0.0:
+                noise = torch.randn_like(st["x"])
+            unet.forward_cl(CL(uin_u, Cx + Cc), st["table"][i], ctx_u, head_out=eps_u)
+            unet.forward_cl(CL(st["unet_in"], Cx + Cc), st["table"][i], st["ctx"], head_out=st["eps"])
+            ops.lincomb4([eps_u, st["eps"]], [1.0 - scale, scale], 1.0, st["eps"])        # (1 - s) e_u + s e_c
+            ops.ddim_step(st["x"].view(M, Cx), st["eps"].view(M, -1), st["scal"][i], noise=noise,
+                          pred_x0_out=st["pred_x0"].view(M, Cx), unet_in=st["unet_in"].view(M, -1))
+            uin_u[..., :Cx].copy_(st["unet_in"][..., :Cx])
+        self.last_step_fused = False
 
     def chain_graphable(self, st, ctx_cl=None, eta=0.0, noise_tape=None) -> bool:
         return bool(self.use_graph and eta == 0.0 and noise_tape is None and (ctx_cl is None or ctx_cl is st["ctx"]) and st["S"] > 2)

@@ -4,9 +4,16 @@ Restates the orchestration of ccdm/ddpm/evaluator.py:127-170 (x_T ~ uniform cate
 latentdiffusion/sample_diffusion.py:196-224 (slice loop: cond = [previous generated slice, mask slice] -> cond stage
 -> DDIM -> decode -> min-max normalise -> feed back), keeping every tensor on the device in channels-last form.
 Volumes are independent units: multi-GPU runs shard volumes over ranks with no collective.
+
+CLI (one process per GPU, under torch.distributed.run or alone):
+    python -m jointimagegeneration_amd.pipeline --volumes V --out DIR [--mask-size D H W] [--depth 256] [--hw 512] [--ccdm-steps 250] [--ddim-steps 50]
+samples volumes `volume_id mod world_size == rank` and writes `mask_<id>.nii.gz` (uint8 labels) and `ct_<id>.nii.gz` (fp32 in [0, 1])
+per volume; volume id v uses seed `--seed + 1000 v` for the mask chain and `+ 1` for the slice loop, whatever the world size.
 """
 from __future__ import annotations
 
+import argparse
+import os
 import sys
 import time
 from typing import Dict, Optional, Tuple
@@ -213,3 +220,50 @@ class GuideGenPipeline:
         self.stats = {"ccdm_s": t1 - t0, "ldm_s": time.time() - t1}
         _log(f"volume done: CCDM {t1 - t0:.1f}s, LDM {time.time() - t1:.1f}s")
         return labels, ct
+
+
+def main(argv=None) -> None:
+    """Sharded full-pipeline entry point (volume_id -> rank = volume_id mod world_size, no collective on the data path)."""
+    from . import distributed as ggd
+    from .io import write_nifti
+    ap = argparse.ArgumentParser(description="GuideGen volumes: CCDM mask -> LDM CT, sharded over the ranks")
+    ap.add_argument("--volumes", type=int, required=True, help="number of volumes of the whole job")
+    ap.add_argument("--out", default="guidegen_out")
+    ap.add_argument("--mask-size", type=int, nargs=3, default=(128, 128, 128))
+    ap.add_argument("--depth", type=int, default=256)
+    ap.add_argument("--hw", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=14)
+    ap.add_argument("--ccdm-steps", type=int, default=250)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=1024)
+    ap.add_argument("--max-slices", type=int, default=None, help="DEV ONLY: truncate the slice loop")
+    args = ap.parse_args(argv)
+    rank, local, world = ggd.env_rank_world()
+    dry = os.environ.get("GG_PIPELINE_DRY") == "1"          # CPU rehearsal of the sharding (tests): no model, no GPU
+    os.makedirs(args.out, exist_ok=True)
+    mine = ggd.shard(args.volumes, rank, world)
+    if dry:
+        ggd.init("gloo")
+        pipe = None
+    else:
+        assert torch.cuda.is_available(), "the GuideGen engine needs an MI355X (no CPU fallback)"
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        ggd.init("nccl", dev)
+        pipe = GuideGenPipeline(build_ccdm(args.classes, args.ccdm_steps, 1024, dev), build_ldm(1024, dev), ddim_steps=args.ddim_steps)
+    t0 = time.time()
+    for vid in mine:
+        seed = args.seed + 1000 * vid
+        if dry:
+            with open(os.path.join(args.out, f"ct_{vid:04d}.txt"), "w") as f:
+                f.write(f"rank {rank} world {world} seed {seed}\n")
+            continue
+        labels, ct = pipe.run_volume(N=1, mask_size=tuple(args.mask_size), depth=args.depth, hw=args.hw, seed=seed, max_slices=args.max_slices)
+        write_nifti(os.path.join(args.out, f"mask_{vid:04d}.nii.gz"), labels[0].to(torch.uint8).cpu().numpy())
+        write_nifti(os.path.join(args.out, f"ct_{vid:04d}.nii.gz"), ct[0].float().cpu().numpy())
+    print(f"[rank {rank}/{world}] volumes {mine} in {time.time() - t0:.1f}s -> {args.out}", file=sys.stderr)
+    ggd.finalize()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -6,8 +6,9 @@ overrides; config = logdir/configs/*.yaml merged (+ dot-list); model = instantia
 checkpoint's "state_dict" loaded strict=False; sampling under model.ema_scope().  `sample_cond` keeps the reference's
 slice loop exactly (Python indexing quirks included) on the reference-shaped API (get_learned_conditioning /
 DDIMSampler.sample / decode_first_stage); `GuideGenPipeline.sample_ct` is the all-device fast path of the same loop.
-Metrics (LPIPS/FVD), PNG grids and the private datasets are out of scope; the mask comes from --mask (.npy label
-volume [D,H,W]) or is synthetic.
+Metrics (LPIPS/FVD), PNG grids and the private datasets are out of scope; the mask comes from `--inputs <dir>` (the
+`pred_*.nii.gz` label volumes the stage-1 entry point ddpm_eval writes: the hand-off of README.md:21, one CT volume per mask),
+from --mask (.npy label volume [D,H,W]) or is synthetic.
 """
 from __future__ import annotations
 
@@ -21,7 +22,8 @@ import numpy as np
 import torch
 
 from .config import apply_dotlist, instantiate_from_config, load_yaml, merge
-from .io import load_checkpoint, write_nifti
+from . import ops
+from .io import load_checkpoint, read_nifti, write_nifti
 from .ldm import DDIMSampler, PLMSSampler
 from .synth import randomize_parameters, synth_mask_volume
 
@@ -37,6 +39,8 @@ def get_parser():
     p.add_argument("-c", "--custom_steps", type=int, nargs="?", default=50, help="number of steps for ddim sampling")
     p.add_argument("--batch_size", type=int, nargs="?", default=1)
     p.add_argument("--config", type=str, default=None, help="model yaml when -r is not a log directory")
+    p.add_argument("--inputs", type=str, default=None, help="directory of stage-1 label volumes (*.nii.gz / *.nii, as ddpm_eval writes them): "
+                   "each is zoomed (order 0) to --slices x --size x --size, rotated and scaled as the reference recipe does, and gets its own CT volume")
     p.add_argument("--mask", type=str, default=None, help=".npy label volume [D,H,W] (labels 0..11); default synthetic ellipsoids")
     p.add_argument("--slices", type=int, default=64)
     p.add_argument("--size", type=int, default=512)
@@ -74,6 +78,19 @@ def strip_ckpt_paths(cfg):
     if isinstance(cfg, dict):
         return {k: (None if k == "ckpt_path" and isinstance(v, str) and not os.path.exists(v) else strip_ckpt_paths(v)) for k, v in cfg.items()}
     return cfg
+
+
+@torch.no_grad()
+def stage1_mask_to_wholemask(labels, depth: int, hw: int) -> torch.Tensor:
+    """The commented recipe of latentdiffusion/sample_diffusion.py:199-200 on the device: a stage-1 label volume [Dm, Hm, Wm] ->
+    `rot90(scipy.ndimage.zoom(mask, (depth, hw, hw) / mask.shape, order=0), k=3, dims=(1, 2)) / 255` as fp32 [depth, hw, hw], through the
+    glue kernel the all-device pipeline uses per slice (gg_mask_to_cond_slice: scipy's order-0 index rule in IEEE double)."""
+    lab = torch.as_tensor(np.ascontiguousarray(labels)).to(device="cuda", dtype=torch.int32)[None].contiguous()
+    vol = torch.empty((depth, hw, hw), dtype=torch.float32, device=lab.device)
+    scratch = torch.empty((1, 1, hw, hw, 32), dtype=torch.bfloat16, device=lab.device)
+    for d in range(depth):
+        ops.mask_to_cond_slice(lab, d, depth, hw, hw, None, scratch, mask_out=vol[d])
+    return vol
 
 
 @torch.no_grad()
@@ -129,20 +146,27 @@ def main(argv=None):
     config = strip_ckpt_paths(apply_dotlist(config, unknown))
     model, global_step = load_model(config, ckpt)
     print(f"global step: {global_step}", file=sys.stderr)
-    if opt.mask:
-        lab = torch.from_numpy(np.load(opt.mask)).long()
-    else:
-        lab = synth_mask_volume(opt.slices, opt.size, opt.size)
-    instance = {"wholemask": (lab.float() / 255.0)[None, ..., None]}
-    t0 = time.time()
-    pred = sample_cond(model, instance, n_samples=opt.n_samples, ddim_steps=opt.custom_steps, ddim_eta=opt.eta, noise_seed=opt.seed,
-                       vanilla=opt.vanilla_sample, plms=opt.plms)
-    torch.cuda.synchronize()
     out_dir = os.path.join(logdir if logdir != "none" else ".", "samples", f"{global_step:08}")
     os.makedirs(out_dir, exist_ok=True)
-    for ix, x in enumerate(pred):
-        write_nifti(os.path.join(out_dir, f"sample_{ix:04d}.nii.gz"), x[0].float().cpu().numpy())
-    print(f"sampled {tuple(pred.shape)} in {time.time() - t0:.1f}s -> {out_dir}", file=sys.stderr)
+    if opt.inputs:
+        # stage-1 hand-off (README.md:21): one CT volume per label volume found in the directory, in name order; the start latents of
+        # volume i come from the generator seeded with --seed + i
+        files = sorted(f for f in glob.glob(os.path.join(opt.inputs, "*.nii*")) if f.endswith((".nii", ".nii.gz")))
+        if not files:
+            raise SystemExit(f"--inputs {opt.inputs!r}: no *.nii / *.nii.gz label volumes found")
+        jobs = [(os.path.basename(f).split(".nii")[0], stage1_mask_to_wholemask(read_nifti(f), opt.slices, opt.size), opt.seed + i) for i, f in enumerate(files)]
+    else:
+        lab = torch.from_numpy(np.load(opt.mask)).long() if opt.mask else synth_mask_volume(opt.slices, opt.size, opt.size)
+        jobs = [("sample", lab.float() / 255.0, opt.seed)]
+    for stem, wholemask, seed in jobs:
+        instance = {"wholemask": wholemask[None, ..., None]}
+        t0 = time.time()
+        pred = sample_cond(model, instance, n_samples=opt.n_samples, ddim_steps=opt.custom_steps, ddim_eta=opt.eta, noise_seed=seed,
+                           vanilla=opt.vanilla_sample, plms=opt.plms)
+        torch.cuda.synchronize()
+        for ix, x in enumerate(pred):
+            write_nifti(os.path.join(out_dir, f"{stem}_{ix:04d}.nii.gz"), x[0].float().cpu().numpy())
+        print(f"sampled {tuple(pred.shape)} in {time.time() - t0:.1f}s -> {out_dir}/{stem}_*.nii.gz", file=sys.stderr)
 
 
 if __name__ == "__main__":

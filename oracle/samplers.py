@@ -146,12 +146,21 @@ def ldm_alphas_cumprod(betas: np.ndarray) -> np.ndarray:
     return np.cumprod(1.0 - betas, axis=0)
 
 
-def ddim_schedule(alphas_cumprod_f32: torch.Tensor, S: int, eta: float = 0.0, T: int = 1000):
+def ddim_timesteps(method: str, S: int, T: int = 1000) -> np.ndarray:
+    """make_ddim_timesteps (ldm/modules/diffusionmodules/util.py:46-59): 'uniform' = arange(0, T, T // S) + 1,
+    'quad' = (linspace(0, sqrt(0.8 T), S) ** 2).astype(int) + 1."""
+    if method == "uniform":
+        return np.asarray(list(range(0, T, T // S))) + 1
+    if method == "quad":
+        return ((np.linspace(0, np.sqrt(T * .8), S)) ** 2).astype(int) + 1
+    raise NotImplementedError(method)
+
+
+def ddim_schedule(alphas_cumprod_f32: torch.Tensor, S: int, eta: float = 0.0, T: int = 1000, discretize: str = "uniform"):
     """DDIMSampler.make_schedule (ldm/models/diffusion/ddim.py:24-53) with
-    make_ddim_timesteps('uniform') and make_ddim_sampling_parameters (util.py:46-74).
+    make_ddim_timesteps and make_ddim_sampling_parameters (util.py:46-74).
     Input is the model's fp32 `alphas_cumprod` buffer."""
-    c = T // S
-    ts = np.asarray(list(range(0, T, c))) + 1
+    ts = ddim_timesteps(discretize, S, T)
     ac = alphas_cumprod_f32.cpu()
     alphas = ac[ts]
     alphas_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
@@ -175,10 +184,14 @@ def ddim_step(x, e_t, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise):
 
 def ddim_sample(eps_model: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], x_T: torch.Tensor,
                 noises: Sequence[torch.Tensor], alphas_cumprod_f32: torch.Tensor, S: int, eta: float = 0.0,
-                T: int = 1000):
+                T: int = 1000, discretize: str = "uniform", eps_uncond: Callable = None, guidance_scale: float = 1.0):
     """DDIMSampler.ddim_sampling (ddim.py:114-164): time_range = flip(ddim_timesteps);
-    index = total-i-1; one noise tensor consumed per step even at sigma=0 (:201)."""
-    sch = ddim_schedule(alphas_cumprod_f32, S, eta, T)
+    index = total-i-1; one noise tensor consumed per step even at sigma=0 (:201).
+    eps_uncond + guidance_scale: classifier-free guidance e = e_u + s (e_c - e_u) (ddim.py:175-180)."""
+    if eps_uncond is not None and guidance_scale != 1.0:
+        cond_model = eps_model
+        eps_model = lambda x, t: (lambda eu, ec: eu + guidance_scale * (ec - eu))(eps_uncond(x, t), cond_model(x, t))
+    sch = ddim_schedule(alphas_cumprod_f32, S, eta, T, discretize)
     ts = sch["timesteps"]
     total = ts.shape[0]
     img = x_T

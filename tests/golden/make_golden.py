@@ -603,6 +603,55 @@ def fx_autoreg(ldm):
     save("autoreg_small", labels=torch.from_numpy(lab).to(torch.uint8), x_T=xT, samples=samples, ddim_steps=np.array(S_steps))
 
 
+def fx_ddim_options(ldm):
+    """Sampler options of the hot-path DDIMSampler that no shipped config uses (VERDICT r03 missing #3): the "quad" discretisation
+    (util.py:50-52) and classifier-free guidance (ddim.py:175-180), both produced by the REFERENCE sampler on the small LatentDiffusion
+    of fx_chains (same weights, same conditioning inputs), cross-checked against the oracle."""
+    om, at, mo, ae, dm, di, ut = ldm
+    import contextlib
+    import io
+    import unittest.mock as mock
+    out = {}
+    for S_, T_ in ((5, 1000), (10, 1000), (50, 1000), (7, 100)):
+        ts = ut.make_ddim_timesteps("quad", S_, T_, verbose=False)
+        assert np.array_equal(ts, S.ddim_timesteps("quad", S_, T_))
+        out[f"quad_ts_{S_}_{T_}"] = ts
+    cfg_unet = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(LDM_SMALL))
+    cfg_ae = dict(target="ldm.models.autoencoder.AutoencoderKL",
+                  params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL), lossconfig=dict(target="torch.nn.Identity")))
+    cfg_cond = dict(target="ldm.models.autoencoder.AutoencoderKL",
+                    params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL, in_channels=2, out_ch=2), lossconfig=dict(target="torch.nn.Identity")))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = dm.LatentDiffusion(first_stage_config=cfg_ae, cond_stage_config=cfg_cond, unet_config=cfg_unet, linear_start=0.0015, linear_end=0.0195,
+                               timesteps=1000, image_size=8, channels=4, dims=2, first_stage_key="image", cond_stage_key="mask",
+                               num_timesteps_cond=1).eval()
+    randomize_parameters(m, SEED, "ldm_pipe.")
+    gen = g(2048)
+    concat_cond = torch.rand(2, 2, 32, 32, generator=gen)
+    x_T = torch.randn(2, 4, 8, 8, generator=gen)
+    c = m.get_learned_conditioning(concat_cond)
+    uc = m.get_learned_conditioning(torch.zeros_like(concat_cond))          # "no mask, no previous slice" as the unconditional input
+    sd_all = sd_of(m)
+    sd_unet = O.sub_state_dict(sd_all, "model.diffusion_model.")
+    eps_c = lambda x, t: O.unet_forward(sd_unet, torch.cat([x, c], 1), t, model_channels=32, head_channels=32)
+    eps_u = lambda x, t: O.unet_forward(sd_unet, torch.cat([x, uc], 1), t, model_channels=32, head_channels=32)
+    zeros = [torch.zeros(2, 4, 8, 8)] * 8
+    sampler = di.DDIMSampler(m)
+    with mock.patch.object(ut.torch, "randn", lambda *a, **k: torch.zeros(2, 4, 8, 8)):
+        # (i) guidance scale 3 on the uniform 5-step schedule, through the reference's sample()
+        z_cfg, _ = sampler.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T, dims=2,
+                                  unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+        # (ii) the quad schedule: reachable in the reference through make_schedule + ddim_sampling only
+        sampler.make_schedule(ddim_num_steps=6, ddim_discretize="quad", ddim_eta=0.0, verbose=False)
+        z_quad, _ = sampler.ddim_sampling(c, (2, 4, 8, 8), dims=2, x_T=x_T)
+    my_cfg, _ = S.ddim_sample(eps_c, x_T, zeros, m.alphas_cumprod, 5, eps_uncond=eps_u, guidance_scale=3.0)
+    close(my_cfg, z_cfg, 2e-4, "DDIM 5 steps, guidance scale 3")
+    my_quad, _ = S.ddim_sample(eps_c, x_T, zeros, m.alphas_cumprod, 6, discretize="quad")
+    close(my_quad, z_quad, 2e-4, "DDIM 6 steps, quad schedule")
+    out.update(concat_cond=concat_cond, x_T=x_T, c=c, uc=uc, z_cfg=z_cfg, z_quad=z_quad, quad_ts_used=sampler.ddim_timesteps)
+    save("ddim_options", **out)
+
+
 def fx_glue():
     """Stage glue: the recipe of latentdiffusion/sample_diffusion.py:199-200,
     rot90(scipy.ndimage.zoom(mask, target / shape, order=0), dims=(1, 2), k=3) / 255, run with scipy itself."""
@@ -672,6 +721,8 @@ if __name__ == "__main__":
         print("glue"); fx_glue()
     if "autoreg" in which or "small" in which or "all" in which:
         print("autoreg"); fx_autoreg(ldm)
+    if "ddimopt" in which or "small" in which or "all" in which:
+        print("ddim options"); fx_ddim_options(ldm)
     if "c1" in which or "all" in which:
         fx_e2e(dd, oh, un, ldm, {"c1"})
     if "c2" in which or "all" in which:

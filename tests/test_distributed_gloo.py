@@ -107,3 +107,54 @@ def test_bench_gpus_mismatch_and_failed_rank_are_errors():
         r = _run_bench(["--gpus", "2", "--steps", "1"], {"GG_DIST_BACKEND": "gloo"})
         assert r.returncode != 0
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_nifti_reader_is_the_inverse_of_the_writer(tmp_path):
+    """io.read_nifti (the stage-1 -> stage-2 hand-off reads what ddpm_eval wrote; README.md:21, sample_diffusion.py:199): [D, H, W] arrays of
+    every supported dtype through .nii and .nii.gz, and loud errors on what is not a little-endian single-file NIfTI-1 volume."""
+    import numpy as np
+    import pytest
+    sys.path.insert(0, ROOT)
+    from jointimagegeneration_amd.io import read_nifti, write_nifti
+    rng = np.random.default_rng(3)
+    for dt in (np.uint8, np.int16, np.int32, np.float32):
+        a = (rng.random((5, 6, 7)) * 200).astype(dt)
+        for ext in (".nii", ".nii.gz"):
+            f = str(tmp_path / f"v_{np.dtype(dt).name}{ext}")
+            write_nifti(f, a)
+            b = read_nifti(f)
+            assert b.dtype == a.dtype and b.shape == (5, 6, 7) and np.array_equal(a, b)
+    bad = tmp_path / "bad.nii"
+    bad.write_bytes(b"\0" * 400)
+    with pytest.raises(ValueError, match="sizeof_hdr"):
+        read_nifti(str(bad))
+    f = str(tmp_path / "v_uint8.nii")
+    raw = open(f, "rb").read()
+    (tmp_path / "short.nii").write_bytes(raw[:-10])
+    with pytest.raises(ValueError, match="truncated"):
+        read_nifti(str(tmp_path / "short.nii"))
+
+
+def test_pipeline_cli_shards_volumes_over_two_gloo_ranks(tmp_path):
+    """`python -m jointimagegeneration_amd.pipeline --volumes 5` under two ranks (GG_PIPELINE_DRY=1: the sharding, seeds and file naming
+    without a GPU): volume_id mod world_size, every volume exactly once, the seed of a volume independent of the world size."""
+    import subprocess
+    port = _free_port()
+    out = tmp_path / "vols"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GG_PIPELINE_DRY="1",
+                   PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, "-m", "jointimagegeneration_amd.pipeline", "--volumes", "5", "--out", str(out)], env=env, cwd=ROOT))
+    assert [p.wait(timeout=180) for p in procs] == [0, 0]
+    got = {f: (out / f).read_text().split() for f in sorted(os.listdir(out))}
+    assert sorted(got) == [f"ct_{v:04d}.txt" for v in range(5)]
+    for v in range(5):
+        words = got[f"ct_{v:04d}.txt"]                                 # "rank R world W seed S"
+        assert int(words[1]) == v % 2 and int(words[3]) == 2 and int(words[5]) == 1024 + 1000 * v
+    env1 = dict(os.environ, GG_PIPELINE_DRY="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env1.pop(k, None)
+    out1 = tmp_path / "vols1"
+    assert subprocess.call([sys.executable, "-m", "jointimagegeneration_amd.pipeline", "--volumes", "3", "--out", str(out1)], env=env1, cwd=ROOT) == 0
+    assert [(out1 / f"ct_{v:04d}.txt").read_text().split()[5] for v in range(3)] == [str(1024 + 1000 * v) for v in range(3)]

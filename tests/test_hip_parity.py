@@ -870,6 +870,36 @@ def test_ccdm_chain_teacher_forced_and_graph(dev):
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_ddim_quad_schedule_and_classifier_free_guidance_vs_reference_fixture(dev):
+    """The two sampler options of DDIMSampler that no shipped config uses (VERDICT r03 missing #3), against what the REFERENCE sampler produced
+    (tests/golden/ddim_options.npz, make_golden.py fx_ddim_options): the "quad" discretisation (util.py:50-52) and classifier-free guidance
+    e = e_u + s (e_c - e_u) (ddim.py:175-180; two UNet evaluations per step + gg_lincomb4 here).  Tolerance: a bf16 network inside a 5 / 6
+    step chain, as for the plain chain above (3 x its error at scale 3: guidance multiplies the difference of two evaluations)."""
+    from jointimagegeneration_amd.ldm import DDIMSampler, LatentDiffusion
+    g = gold("ddim_options")
+    cfg_unet = dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(LDM_SMALL))
+    cfg_ae = dict(target="ldm.models.autoencoder.AutoencoderKL", params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL), lossconfig=dict(target="torch.nn.Identity")))
+    cfg_cond = dict(target="ldm.models.autoencoder.AutoencoderKL", params=dict(embed_dim=4, dims=2, ddconfig=dict(AE_SMALL, in_channels=2, out_ch=2), lossconfig=dict(target="torch.nn.Identity")))
+    m = seeded(LatentDiffusion(first_stage_config=cfg_ae, cond_stage_config=cfg_cond, unet_config=cfg_unet, linear_start=0.0015,
+                               linear_end=0.0195, timesteps=1000, image_size=8, channels=4, dims=2, first_stage_key="image",
+                               cond_stage_key="mask", num_timesteps_cond=1), "ldm_pipe.").to(dev)
+    c, uc, x_T = T(g["c"]).to(dev), T(g["uc"]).to(dev), T(g["x_T"]).to(dev)       # the REFERENCE's conditionings: the samplers alone are compared
+    sampler = DDIMSampler(m)
+    z_cfg, _ = sampler.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T, dims=2,
+                              unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    e1, r1 = rel_err(z_cfg, T(g["z_cfg"])), rms_err(z_cfg, T(g["z_cfg"]))
+    z_plain, _ = sampler.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T, dims=2)
+    assert rel_err(z_plain, T(g["z_cfg"])) > 5 * e1                                   # guidance really changed the sample
+    z_one, _ = sampler.sample(S=5, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T, dims=2,
+                              unconditional_guidance_scale=1.0, unconditional_conditioning=uc)
+    assert torch.equal(z_one, z_plain)                                                # scale 1 is the unguided path (ddim.py:172)
+    z_quad, _ = sampler.sample(S=6, batch_size=2, shape=(4, 8, 8), conditioning=c, verbose=False, x_T=x_T, dims=2, ddim_discretize="quad")
+    assert np.array_equal(sampler.ddim_timesteps, g["quad_ts_used"])
+    e2, r2 = rel_err(z_quad, T(g["z_quad"])), rms_err(z_quad, T(g["z_quad"]))
+    print(f"DDIM guidance scale 3: max {e1:.3e} rms {r1:.3e}; quad schedule: max {e2:.3e} rms {r2:.3e} (of the reference's max)")
+    assert e1 < 6e-2 and r1 < 3e-2 and e2 < 2e-2 and r2 < 1.5e-2
+
+
 def test_ldm_pipeline_ddim_chain(dev):
     from jointimagegeneration_amd.ldm import DDIMSampler, LatentDiffusion
     g = gold("chains_small")
@@ -1274,3 +1304,45 @@ def test_team_halo_conv_bit_identical_to_halo_kernel(dev, case):
         ops.PATH_HINT = old
     assert torch.equal(outs[1], outs[7])
     assert float((sums[1] - sums[7]).abs().max()) <= 2e-6 * float(sums[1].abs().max())
+
+
+@pytest.mark.gpu
+def test_stats_arena_is_replay_safe_when_a_forward_is_captured_cold(dev):
+    """ops.stats_begin zeroed only the arena prefix below the high-water mark, so a forward CAPTURED without an eager
+    run before it (mark 0: no memset captured at all) replayed onto its own previous GroupNorm sums.  While capturing, the whole arena is
+    zeroed now: a conv that leaves its sums (gg_conv_desc.gn_acc), captured cold and replayed three times, must leave the same sums as
+    the eager launch every time."""
+    from jointimagegeneration_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = ops.CL(torch.randn((1, 1, 32, 32, 160), generator=g).to(dev).bfloat16(), 160)
+    w = torch.randn(160, 160, 3, 3, generator=g).to(dev) / math.sqrt(160 * 9)
+    pw = ops.pack_conv_weight(w, 160)
+    pb = ops.pad_bias(None, 160, dev)
+    keep = {}
+
+    def fwd():
+        ops.stats_begin(dev)
+        y = ops.conv(x, pw, pb, 160, k=(1, 3, 3), want_stats=True)
+        ops.stats_end(dev)
+        keep["y"] = y
+        return y
+
+    ops._ARENAS.pop(str(dev), None)                  # a process that has never run a forward: high-water mark 0
+    ops.stats_begin(dev); ops.stats_end(dev)         # (only the arena allocation, outside the capture)
+    assert ops._ARENAS[str(dev)]["hi"] == 0
+    torch.cuda.synchronize()
+    graph = ops.capture_graph(fwd)                   # cold capture: no eager forward before it
+    acc_view = keep["y"].acc
+    assert acc_view is not None, "the box conv did not leave its sums"
+    sums = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        sums.append(acc_view.clone())
+    torch.cuda.synchronize()
+    y = fwd()
+    torch.cuda.synchronize()
+    want = y.acc.clone()
+    assert int(want.abs().sum()) != 0
+    for i, s_ in enumerate(sums):
+        assert torch.equal(s_, want), f"replay {i}: GroupNorm sums differ from the eager launch (stale accumulators folded in)"

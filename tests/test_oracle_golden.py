@@ -298,3 +298,17 @@ def test_autoregressive_slice_loop_oracle_vs_reference_fixture():
     assert mine.shape == ref.shape == (1, 1, 11, 32, 32)
     assert float(per_slice.max()) < 2e-4, per_slice
     assert float(ref[0, 0, :].flatten(1).max(1).values.min()) == 1.0            # every slice was generated and min-max normalised
+
+
+def test_quad_ddim_timesteps_match_reference_fixture():
+    """make_ddim_timesteps("quad") (util.py:50-52) of the oracle AND of the product's host logic against the reference's arrays
+    (tests/golden/ddim_options.npz)."""
+    from jointimagegeneration_amd.ldm import make_ddim_timesteps
+    g = gold("ddim_options")
+    for key in [k for k in g.files if k.startswith("quad_ts_") and k != "quad_ts_used"]:
+        S_, T_ = (int(v) for v in key.split("_")[2:])
+        assert np.array_equal(S.ddim_timesteps("quad", S_, T_), g[key])
+        assert np.array_equal(make_ddim_timesteps("quad", S_, T_, verbose=False), g[key])
+    assert np.array_equal(make_ddim_timesteps("uniform", 50, 1000), np.arange(0, 1000, 20) + 1)
+    with pytest.raises(NotImplementedError):
+        make_ddim_timesteps("cosine", 10, 1000)
