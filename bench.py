@@ -205,12 +205,18 @@ def conv_roofline(pipe, device):
            "traffic": None, "launches": len(halo), "avg_launch_ms": round(t / len(halo) * 1e3, 4), "flops_per_launch": round(fl / len(halo)),
            "all_3x3x3_convs": {"launches": len(k27), "achieved": round(fl27 / t27 / 1e12, 1), "flops_per_forward": fl27},
            "eager_forward_ms_with_event_pairs": round(ef0.elapsed_time(ef1), 2)}
-    for name in ("r03/pmc_conv3d.json", "r02/pmc_conv3d.json", "r01_pmc_conv3d.json"):
+    for name in ("r04/pmc_conv3d.json", "r03/final_pmc_conv3d.json", "r03/pmc_conv3d.json", "r02/pmc_conv3d.json", "r01_pmc_conv3d.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             j = json.load(open(pmc))
             out["traffic"] = j["traffic_bytes_per_launch"]
             out["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+            # the counters belong to ONE version of the kernel: say whether the source this run was built from still is that version
+            import hashlib
+            src = os.path.join(ROOT, "jointimagegeneration_amd", "csrc", "gg_conv_halo.hip")
+            sha = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+            out["traffic_kernel_source_sha256"] = j.get("kernel_source_sha256")
+            out["traffic_matches_this_source"] = (sha is not None and sha == j.get("kernel_source_sha256"))
             break
     return out
 

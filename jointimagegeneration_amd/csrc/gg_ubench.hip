@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void ubench_mfma_kernel(const int iters, float
 __global__ __launch_bounds__(256) void ubench_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, const long long n16)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    // non-temporal loads and stores, 4 workgroups per CU: the fastest of the forms tried (tools/experiments/ubench_copy.hip: 6.3 TB/s;
+    // 8-64 workgroups per CU or 2-8 loads in flight per thread: 4.7-5.6)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" int gg_ubench_mfma_bf16(int32_t shape, int32_t iters, int32_t waves_per_simd, float *sink, double *flops_out, void *stream)
@@ -90,7 +92,7 @@ extern "C" int gg_ubench_stream_copy(const void *src, void *dst, int64_t bytes, 
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         GG_FAIL(GG_ERR_HIP, "gg_ubench_stream_copy: device query failed");
-    hipLaunchKernelGGL(ubench_copy_kernel, dim3(cus * 16), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)src, (u32x4 *)dst, (long long)(bytes >> 4));
+    hipLaunchKernelGGL(ubench_copy_kernel, dim3(cus * 4), dim3(256), 0, (hipStream_t)stream, (const u32x4 *)src, (u32x4 *)dst, (long long)(bytes >> 4));
     GG_CHECK_LAUNCH();
     return GG_OK;
 }

@@ -37,6 +37,10 @@ template <int PAD, int LAST> int run()
     CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("parameter struct %4zu bytes, last field %s  %7.3f us per launch (host time inside hipGraphLaunch: %.3f us per node)\n", sizeof(Args<PAD>), LAST ? "read  " : "unread", ms * 1e3 / (50.0 * L), cpu_us / (50.0 * L));
+    // every object of this case is released again (the ten cases used to leak their graph, exec, stream and events)
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    CK(hipStreamDestroy(st));
     CK(hipFree(a)); CK(hipFree(b));
     return 0;
 }

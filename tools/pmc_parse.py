@@ -5,7 +5,7 @@ Commands that produced the passes (GPU box):
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python tools/perf_probe.py ccdm128
 gfx950 corrections: FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) reads => doubled; WRITE_SIZE is exact
 for 16-B stores; both are in KiB."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
 
 
 def load(d, name):
@@ -29,5 +29,10 @@ out = {"kernel": "conv_halo_kernel<3-D> (all instantiations) in CCDM UNet forwar
        "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1; separate --pmc passes",
        "per_shape": [{"kernel": k[0], "grid_threads": k[1], "launches": F[k][0], "fetch_KiB_raw": round(F[k][1] / F[k][0]),
                       "write_KiB": round(W[k][1] / W[k][0]) if k in W else None} for k in sorted(F, key=lambda k: -F[k][1])]}
+# stamp WHICH kernel source the counters belong to: bench.py quotes this file as `roofline.traffic` and says whether the source it runs
+# still is the one that was measured
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jointimagegeneration_amd", "csrc", "gg_conv_halo.hip")
+out["kernel_source"] = "jointimagegeneration_amd/csrc/gg_conv_halo.hip"
+out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out)[:600])
