@@ -250,7 +250,7 @@ int gg_cl_to_nchw_f32(const void *src, int32_t src_dtype, int32_t N, int32_t C, 
  *   draw       1: sample (t > 1); 0: argmax of the normalised posterior (t == 1)
  *   scalars    device fp32[2] = {alphas[t-1] (0 at t==1), cumalphas[t-2] (1 at t==1)}
  * Outputs: labels_out int32 [M] (may alias xt); probs_out fp32 [M, K] normalised posterior or NULL;
- *          onehot_out bf16 CL [M, onehot_stride] (channels < K one-hot, rest untouched) or NULL.
+ *          onehot_out bf16 CL [M, onehot_stride] (channels < K one-hot, rest untouched; onehot_stride even, rows 4-byte aligned) or NULL.
  * ------------------------------------------------------------------------------------------------ */
 int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, int32_t head_is_logits, const int32_t *xt,
                              const float *E, uint64_t philox_seed, const int64_t *philox_offset_dev, int32_t draw,

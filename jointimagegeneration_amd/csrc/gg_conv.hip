@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
     // ---- epilogue: + bias[n] (+ residual) -> bf16 / fp32, 4 consecutive channels per lane.  Every bias / residual load stands in front of
     // the first store: gfx950 counts loads and stores in one in-order counter, so a load behind a store waits for the store's round trip
     f32x4 bv[2][2 * NT];
-    bf16x4 rv[2][2 * NT];
+    bf16x4 resv[2][2 * NT];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const long long m = m0 + wave * 32 + pt * 16 + fr;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
         for (int ct = 0; ct < 2 * NT; ++ct) {
             const int co = (g0 * 32) + ct * 16 + fq * 4;
             bv[pt][ct] = brow ? *reinterpret_cast<const f32x4 *>(brow + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.residual) rv[pt][ct] = *reinterpret_cast<const bf16x4 *>(p.residual + mc * p.Cout_pad + co);
+            if (p.residual) resv[pt][ct] = *reinterpret_cast<const bf16x4 *>(p.residual + mc * p.Cout_pad + co);
         }
     }
 #pragma unroll
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvParams p)
             if (p.bias) v += bv[pt][ct];
             long long o = m * p.Cout_pad + co;
             if (p.residual) {
-                const bf16x4 r = rv[pt][ct];
+                const bf16x4 r = resv[pt][ct];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
             }

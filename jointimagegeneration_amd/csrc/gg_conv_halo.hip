@@ -19,6 +19,9 @@
 #ifndef GG_HALO_G3_2D
 #define GG_HALO_G3_2D 1        /* the same for the 2-D kernel at NT >= 3 (AE convs; same-box A/B: decode 4.137 -> 4.05 ms, cond-encode 1.79 -> 1.75 ms) */
 #endif
+#ifndef GG_HALO_TSTORE
+#define GG_HALO_TSTORE 1       /* epilogue stores and residual loads transposed through LDS into full-line runs (0: straight in the accumulator layout) */
+#endif
 #ifndef GG_HALO_W16_2D
 #define GG_HALO_W16_2D 1
 #endif
@@ -283,13 +286,34 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
         // couts; the operand fragments are dead by now): ONE memory round trip in front of the stores instead of one per tile row
         // (NT >= 3: 64 statistics + 32 bias registers beside the 128 accumulators leave no room for that; there the pieces of tile row
         // tt + 1 are requested before the stores of row tt, so that the wait for them skips those stores)
+        // Output stores (bf16) go through LDS: the MFMA accumulator layout gives every lane 4 couts of ONE position, i.e. a store
+        // instruction of 16 scattered 32-byte segments, 2 NT of them per tile row; transposed through a per-wave scratch (the box image
+        // is dead by now) a tile row leaves as NT instructions of 16 bytes per lane that cover whole 64 NT-byte runs per position (one
+        // 2 KiB run where the wave owns all couts).  Scratch rows are padded by 16 B: conflict-free 8-byte writes for NT 1..4.
+        // Measured (same-box A/B): 64->64 @128^3 with residual 566 -> 530 us, without 487 -> 476; on the 512-position boxes (NT 3 / 4) and
+        // in 2-D it is 1-2 % SLOWER (shorter epilogues, and NT 3 spills 50 registers), so only the 1024-position boxes take it.
+        constexpr bool TS = GG_HALO_TSTORE && D3 && HB == 2;
+        constexpr int TS_PPR = 4 * NT, TS_RS = 64 * NT + 16;
+        char *scr = smem + 8192 + wave * (16 * TS_RS);      // the first 8 KiB take the statistics exchange below
         constexpr bool ALLRES = NT <= 2;
         constexpr int RD = ALLRES ? TPW : 2;
-        bf16x4 rres[RD][2 * NT];
+        // the residual comes in the same way: NT 16-byte pieces per lane in memory order, redistributed to the accumulator layout
+        // through the wave's scratch rows
+        u32x4 rres16[TS ? RD : 1][NT];
+        bf16x4 rres[TS ? 1 : RD][2 * NT];
         auto prefetch = [&](int tt) {
-            const long long o1 = out_off(tt);
+            if constexpr (TS) {
+                const long long mrow = out_off(tt) - (long long)fr * p.Cout_pad - fq * 4;
 #pragma unroll
-            for (int ct = 0; ct < 2 * NT; ++ct) rres[tt % RD][ct] = *reinterpret_cast<const bf16x4 *>(p.residual + o1 + ct * 16);
+                for (int i = 0; i < NT; ++i) {
+                    const int idx = i * 64 + lane, pos = idx / TS_PPR, pc = idx - pos * TS_PPR;
+                    rres16[tt % RD][i] = *reinterpret_cast<const u32x4 *>(p.residual + mrow + (long long)pos * p.Cout_pad + pc * 8);
+                }
+            } else {
+                const long long o1 = out_off(tt);
+#pragma unroll
+                for (int ct = 0; ct < 2 * NT; ++ct) rres[tt % RD][ct] = *reinterpret_cast<const bf16x4 *>(p.residual + o1 + ct * 16);
+            }
         };
         if (p.residual) {
 #pragma unroll
@@ -299,6 +323,13 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
         for (int tt = 0; tt < TPW; ++tt) {
             const long long ob = out_off(tt);
             if (!ALLRES && p.residual && tt + 1 < TPW) prefetch(tt + 1);
+            if (TS && p.residual) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int idx = i * 64 + lane, pos = idx / TS_PPR, pc = idx - pos * TS_PPR;
+                    *reinterpret_cast<u32x4 *>(scr + pos * TS_RS + pc * 16) = rres16[TS ? tt % RD : 0][i];
+                }
+            }
 #pragma unroll
             for (int ct = 0; ct < 2 * NT; ++ct) {
                 const int co = g0 * 32 + ct * 16 + fq * 4;
@@ -306,7 +337,7 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
                 if (brow) v += bvec[ct];
                 const long long o = ob + ct * 16;
                 if (p.residual) {
-                    const bf16x4 r = rres[tt % RD][ct];
+                    const bf16x4 r = TS ? *reinterpret_cast<const bf16x4 *>(scr + fr * TS_RS + (ct * 16 + fq * 4) * 2) : rres[TS ? 0 : tt % RD][ct];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                 }
@@ -324,44 +355,76 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
                         ssum[ct][j] += f;
                         ssq[ct][j] += f * f;
                     }
-                    *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob4;
+                    if constexpr (TS) *reinterpret_cast<bf16x4 *>(scr + fr * TS_RS + (ct * 16 + fq * 4) * 2) = ob4;
+                    else *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob4;
+                }
+            }
+            if (TS && p.out_dtype != GG_F32) {
+                // the tile row (16 positions x 32 NT couts) back out of LDS as 16-byte pieces in memory order: position = idx / PPR
+                const long long mrow = ob - (long long)fr * p.Cout_pad - fq * 4;          // element offset of (position 0, cout g0 * 32)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int idx = i * 64 + lane, pos = idx / TS_PPR, pc = idx - pos * TS_PPR;
+                    const u32x4 v16 = *reinterpret_cast<const u32x4 *>(scr + pos * TS_RS + pc * 16);
+                    *reinterpret_cast<u32x4 *>((bf16_t *)p.out + mrow + (long long)pos * p.Cout_pad + pc * 8) = v16;
                 }
             }
         }
     } else {
-        // (16 waves at a 128-register budget: two tile rows per wave, no room for a hoisted bias vector set; the loop is two rows short anyway)
-#pragma unroll
-        for (int tt = 0; tt < TPW; ++tt) {
+        // 16 waves at a 128-register budget (64 accumulator + 64 statistics registers at NT 4): no room for whole vector sets, so the bias
+        // and residual piece of tile k + 1 are requested before tile k is stored -- ONE tile of look-ahead (6 registers): the wait for them
+        // then skips that store instead of waiting for its round trip
+        constexpr int NTILE = TPW * 2 * NT;
+        auto tile_off = [&](int k, long long &o, int &co) {
+            const int tt = k / (2 * NT), ct = k - tt * (2 * NT);
             const int tile = wave * TPW + tt;
             const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
             const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + fr);
+            co = g0 * 32 + ct * 16 + fq * 4;
+            o = m * p.Cout_pad + co;
+        };
+        f32x4 bnx = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 rnx = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        {
+            long long o0; int c0;
+            tile_off(0, o0, c0);
+            if (brow) bnx = *reinterpret_cast<const f32x4 *>(brow + c0);
+            if (p.residual) rnx = *reinterpret_cast<const bf16x4 *>(p.residual + o0);
+        }
 #pragma unroll
-            for (int ct = 0; ct < 2 * NT; ++ct) {
-                const int co = g0 * 32 + ct * 16 + fq * 4;
-                f32x4 v = acc[tt][ct];
-                if (brow) v += *reinterpret_cast<const f32x4 *>(brow + co);
-                const long long o = m * p.Cout_pad + co;
-                if (p.residual) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + o);
+        for (int k = 0; k < NTILE; ++k) {
+            const int tt = k / (2 * NT), ct = k - tt * (2 * NT);
+            long long o; int co;
+            tile_off(k, o, co);
+            const f32x4 bcur = bnx;
+            const bf16x4 rcur = rnx;
+            if (k + 1 < NTILE) {
+                long long o1; int c1;
+                tile_off(k + 1, o1, c1);
+                if (brow) bnx = *reinterpret_cast<const f32x4 *>(brow + c1);
+                if (p.residual) rnx = *reinterpret_cast<const bf16x4 *>(p.residual + o1);
+            }
+            f32x4 v = acc[tt][ct];
+            if (brow) v += bcur;
+            if (p.residual) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                for (int j = 0; j < 4; ++j) v[j] += (float)rcur[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co + j >= p.Cout) v[j] = 0.f;
+            if (p.out_dtype == GG_F32) {
+                *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
+            } else {
+                bf16x4 ob;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ob[j] = (bf16_t)v[j];
+                    const float f = (float)ob[j];               // what the next norm will read
+                    ssum[ct][j] += f;
+                    ssq[ct][j] += f * f;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (co + j >= p.Cout) v[j] = 0.f;
-                if (p.out_dtype == GG_F32) {
-                    *reinterpret_cast<f32x4 *>((float *)p.out + o) = v;
-                } else {
-                    bf16x4 ob;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ob[j] = (bf16_t)v[j];
-                        const float f = (float)ob[j];               // what the next norm will read
-                        ssum[ct][j] += f;
-                        ssq[ct][j] += f * f;
-                    }
-                    *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
-                }
+                *reinterpret_cast<bf16x4 *>((bf16_t *)p.out + o) = ob;
             }
         }
     }

@@ -117,9 +117,21 @@ __global__ __launch_bounds__(256) void ccdm_posterior_kernel(const float *__rest
     }
     labels_out[m] = best;
     if (onehot_out) {
+        // channels [0, K) of the voxel's row as 4-byte pairs (+ one 2-byte tail for odd K): 7 stores instead of 14 two-byte ones at K = 14
+        // (two-byte stores cost ~12x a 16-byte store per byte on this memory system, MI355X_MICROARCH.md); channel K and beyond (the
+        // condition image, the padding lanes) are NOT touched
         bf16_t *oh = onehot_out + m * onehot_stride;
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) if (c < K) oh[c] = (bf16_t)(c == best ? 1.0f : 0.0f);
+        for (int c = 0; c + 1 < KMAX; c += 2) {
+            if (c + 1 < K) {
+                bf16x2 pr;
+                pr[0] = (bf16_t)(c == best ? 1.0f : 0.0f);
+                pr[1] = (bf16_t)(c + 1 == best ? 1.0f : 0.0f);
+                *reinterpret_cast<bf16x2 *>(oh + c) = pr;
+            } else if (c < K) {
+                oh[c] = (bf16_t)(c == best ? 1.0f : 0.0f);
+            }
+        }
     }
 }
 
@@ -133,6 +145,7 @@ extern "C" int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, 
     if (K < 2 || K > 32) GG_FAIL(GG_ERR_UNSUPPORTED, "ccdm_posterior_sample: K=%d outside [2, 32]", K);
     if (head_stride < K) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: head_stride < K");
     if (onehot_out && onehot_stride < K) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: onehot_stride < K");
+    if (onehot_out && ((onehot_stride & 1) || ((uintptr_t)onehot_out & 3))) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: onehot rows must be 4-byte aligned (even stride)");
     if (M <= 0) return GG_OK;
     dim3 grid((unsigned)((M + 255) / 256));
     if (K <= 16)
