@@ -176,7 +176,7 @@ def conv_roofline(pipe, device):
     real_conv = ops.conv
 
     def timed_conv(src1, weight, bias, cout, k=(1, 3, 3), stride=1, pad=1, upsample=False, src2=None, **kw):
-        halo = ops.conv_fuses_prologue(src1, cout, k=k, stride=stride, pad=pad, upsample=upsample, src2=src2)
+        halo = ops.conv_runs_halo_tile(src1, cout, k=k, stride=stride, pad=pad, upsample=upsample, src2=src2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = real_conv(src1, weight, bias, cout, k=k, stride=stride, pad=pad, upsample=upsample, src2=src2, **kw)

@@ -127,6 +127,24 @@ typedef struct {
     const void *skip_src1;       /* bf16 CL [N,D,H,W,skip_C1] (same extent as the conv's input)            */
     const void *skip_src2;       /* bf16 CL [N,D,H,W,skip_C2] or NULL                                      */
     const void *skip_weight;
+    /* Optional fused CCDM reverse step as the epilogue of the UNet HEAD conv (ccdm/ddpm/models/DenoisingModel: softmax of the head,
+     * posterior q(x_{t-1} | x_t, x_0) summed over the predicted x_0, categorical draw; replaces a separate gg_ccdm_posterior_sample launch and
+     * the round trip of the fp32 logits, 128 B per voxel).  Only when gg_conv_fuses_posterior(desc) == 1 (halo-tile kernel with the
+     * 1024-position 3-D box, Cout = K <= 16, fp32 output, no residual).  For every output position m (= voxel index n, d, h, w) the
+     * epilogue runs, on the fp32 accumulator + bias (the logits), exactly the arithmetic of gg_ccdm_posterior_sample (same device
+     * function, so the same labels bit for bit), writes the new label to post_labels_out[m] (may alias post_xt) and, when
+     * post_onehot_out != NULL, channels [0, K) of row m of the one-hot UNet input (bf16, row stride post_onehot_stride, even).
+     * `out` is NOT written in this mode (may be NULL).  post_xt == NULL: plain conv. */
+    const int32_t *post_xt;        /* int32 [M] current labels x_t                                            */
+    int32_t *post_labels_out;      /* int32 [M]                                                               */
+    const float *post_scalars;     /* device fp32[2], as gg_ccdm_posterior_sample's scalars_dev               */
+    const float *post_E;           /* optional fp32 [M, K] exponentials (a tape); NULL: Philox                */
+    uint64_t post_philox_seed;
+    const int64_t *post_philox_offset_dev;   /* device int64[1] step offset of the Philox counter, or NULL (0)  */
+    void *post_onehot_out;         /* bf16 [M, post_onehot_stride] or NULL                                    */
+    int64_t post_onehot_stride;
+    int32_t post_draw;             /* 1: categorical draw (exponential race); 0: argmax of the posterior      */
+    int32_t reserved_tail2;
 } gg_conv_desc;
 
 /* Bytes of the packed weight for a conv with the given logical shape. */
@@ -138,9 +156,15 @@ int gg_conv_pack_weight(const float *w_f32, int32_t Cout, int32_t Cin, int32_t C
                         void *packed_bf16, void *stream);
 /* Scratch bytes gg_conv_forward needs for this shape (0 for most; > 0 when the under-filled grid is split over K). */
 int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
-/* 1 if this shape runs on the halo-tile kernel, where the GroupNorm prologue is applied once per staged element (callers
- * then skip the separate gg_groupnorm_apply pass); 0 if it runs on the generic gather kernel. Pointers are not read. */
+/* 1 if the caller should hand the GroupNorm (* SiLU) in front of this conv to the conv (gn_scale / gn_shift + prologue_act: applied
+ * once per staged element, the normalised activation never written to HBM), 0 if a separate gg_groupnorm_apply pass in front of a
+ * prologue-free conv is the faster form.  Halo-tile shapes CAN always fuse it (path_hint != 0 answers that); with path_hint 0 the answer
+ * follows the measured rule in gg_conv_halo.hip (separate where a box is re-staged by several cout groups).  Box-kernel shapes: where the box is staged by at most two cout tiles.  Pointers are not read. */
 int gg_conv_fuses_prologue(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) can run the CCDM reverse step as this (head) conv's epilogue (gg_conv_desc.post_xt). Pointers are not read. */
+int gg_conv_fuses_posterior(const gg_conv_desc *desc);
+/* 1 if gg_conv_forward(desc) runs this shape on the halo-tile kernel (3x3(x3), stride 1, filled grid). Pointers are not read. */
+int gg_conv_runs_halo_tile(const gg_conv_desc *desc);
 /* 0 if gg_conv_forward(desc) will not fill desc->gn_acc, else the number of stripes S of the [N][S][Cout_pad][2] accumulator it fills
  * (1 for the box / 160-step kernels, 32 for the halo-tile kernel); pointers are not read. */
 int gg_conv_emits_stats(const gg_conv_desc *desc);

@@ -27,6 +27,8 @@ class ConvDesc(C.Structure):
         ("ddim_x", vp), ("ddim_scalars", vp), ("ddim_pred_x0", vp), ("ddim_unet_in", vp), ("ddim_unet_in_stride", i64),
         ("epilogue_geglu", i32), ("pro_c_logical", i32), ("pro_acc1", vp), ("pro_acc2", vp), ("pro_gamma", vp), ("pro_beta", vp),
         ("pro_eps", f32), ("skip_C1", i32), ("skip_C2", i32), ("reserved_tail", i32), ("skip_src1", vp), ("skip_src2", vp), ("skip_weight", vp),
+        ("post_xt", vp), ("post_labels_out", vp), ("post_scalars", vp), ("post_E", vp), ("post_philox_seed", C.c_uint64),
+        ("post_philox_offset_dev", vp), ("post_onehot_out", vp), ("post_onehot_stride", i64), ("post_draw", i32), ("reserved_tail2", i32),
     ]
 
 
@@ -48,10 +50,12 @@ SIGNATURES = {
     "gg_conv_forward": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "gg_conv_workspace_bytes": (i64, [C.POINTER(ConvDesc)]),
     "gg_conv_fuses_prologue": (C.c_int, [C.POINTER(ConvDesc)]),
+    "gg_conv_runs_halo_tile": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_emits_stats": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_prologue_from_acc": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_fuses_skip": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_conv_fuses_ddim": (C.c_int, [C.POINTER(ConvDesc)]),
+    "gg_conv_fuses_posterior": (C.c_int, [C.POINTER(ConvDesc)]),
     "gg_groupnorm_workspace_bytes": (i64, [i32, i64, i32]),
     "gg_groupnorm_stats": (C.c_int, [vp, i32, vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i64, vp]),
     "gg_groupnorm_apply": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, vp, i32, vp, vp]),

@@ -136,7 +136,7 @@ def norm_conv(h: CL, norm: nn.GroupNorm, act: bool, weight, bias, cout, src2: Op
     if not fused and ops.has_stats(h, src2):     # statistics came with the tensor (conv epilogue accumulators)
         a = ops.groupnorm_apply_acc(h, f32(norm.weight), f32(norm.bias), norm.eps, act, src2)
         return ops.conv(a, weight, bias, cout, **conv_kw)
-    if fused and ops.has_any_stats(h, src2):     # halo-tile producers: fold their sums instead of re-reading 17..805 MB per norm
+    if ops.has_any_stats(h, src2):     # halo-tile producers: fold their sums instead of re-reading 17..805 MB per norm
         scale, shift = ops.groupnorm_scale_shift_acc(h, f32(norm.weight), f32(norm.bias), norm.eps, src2)
     else:
         scale, shift = ops.groupnorm_stats(h, f32(norm.weight), f32(norm.bias), norm.eps, src2)

@@ -172,8 +172,15 @@ class DenoisingModel(nn.Module):
         xcl = CL(xin, cin)
 
         def step(draw: bool, E=None, want_probs=False):
-            unet.forward_cl(xcl, cur_bias, head_out=logits)
             bf16_in = xin.dtype == torch.bfloat16
+            # softmax + posterior + draw as the head conv's epilogue where the kernel can (ops.conv `post`): the fp32 logits (128 B per
+            # voxel) are then never written; steps that return the posterior itself (the last one, traces) take the sampler kernel
+            post = dict(xt=lab, scalars=cur_scal, K=K, E=E, philox_seed=self.philox_seed, philox_offset=cur_off, draw=draw, labels_out=lab,
+                        onehot_out=xin.view(M, -1)) if (bf16_in and not want_probs) else None
+            head = unet.forward_cl(xcl, cur_bias, head_out=logits, head_post=post)
+            self.last_step_fused = head.fused_post
+            if head.fused_post:
+                return
             ops.ccdm_posterior_sample(logits.view(M, -1), True, lab, cur_scal, K, E=E, philox_seed=self.philox_seed,
                                       philox_offset=cur_off, draw=draw, labels_out=lab,
                                       probs_out=probs if want_probs else None, onehot_out=xin.view(M, -1) if bf16_in else None)

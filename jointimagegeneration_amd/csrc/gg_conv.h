@@ -31,6 +31,15 @@ struct ConvParams {
     // K-concatenated 1x1 skip projection (gg_conv_desc.skip_src1; box kernel, 3x3 stride 1 only)
     const bf16_t *skip_src1, *skip_src2, *skip_weight;
     int skip_C1, skip_C2;
+    // fused CCDM reverse step of the UNet head conv (gg_conv_desc.post_xt; halo-tile kernel, 1024-position 3-D box only)
+    const int *post_xt;
+    int *post_labels_out;
+    const float *post_scalars, *post_E;
+    unsigned long long post_seed;
+    const long long *post_offset_dev;
+    bf16_t *post_onehot_out;
+    long long post_onehot_stride;
+    int post_draw;
 };
 
 // fixed-point scales of the GroupNorm accumulators: |sum| < 2^35, sumsq < 2^43 per channel and sample

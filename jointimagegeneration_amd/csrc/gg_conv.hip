@@ -629,6 +629,10 @@ extern "C" int gg_conv_pack_weight(const float *w, int32_t Cout, int32_t Cin, in
 
 // halo fast path (gg_conv_halo.hip); returns GG_ERR_UNSUPPORTED when the shape is outside its envelope
 int gg_conv_halo_try(const ConvParams &p, hipStream_t stream);
+bool gg_conv_halo_prefers_separate_norm(const ConvParams &p);
+#ifndef GG_HALO_SEPARATE_NORM
+#define GG_HALO_SEPARATE_NORM 1      /* A/B switch: 0 = halo-tile convs always fuse the GroupNorm prologue */
+#endif
 // box-resident 2-D path for under-filled grids (gg_conv_box.hip); same contract as gg_conv_halo_try
 int gg_conv_box_try(const ConvParams &p, hipStream_t stream);
 bool gg_conv_box_fuses_prologue(const ConvParams &p);
@@ -728,17 +732,29 @@ static void fill_params(const gg_conv_desc *d, ConvParams &p)
     if (d->gn_scale || d->gn_shift || !d->prologue_act) p.pro_acc1 = p.pro_acc2 = nullptr;          // external tables win; no prologue: unused
     p.skip_src1 = (const bf16_t *)d->skip_src1; p.skip_src2 = (const bf16_t *)d->skip_src2; p.skip_weight = (const bf16_t *)d->skip_weight;
     p.skip_C1 = d->skip_C1; p.skip_C2 = d->skip_C2;
+    p.post_xt = d->post_xt; p.post_labels_out = d->post_labels_out; p.post_scalars = d->post_scalars; p.post_E = d->post_E;
+    p.post_seed = d->post_philox_seed; p.post_offset_dev = (const long long *)d->post_philox_offset_dev;
+    p.post_onehot_out = (bf16_t *)d->post_onehot_out; p.post_onehot_stride = d->post_onehot_stride; p.post_draw = d->post_draw;
     p.mg_osp = gg_magic_u32(p.M, d->Do * d->Ho * d->Wo); p.mg_ohw = gg_magic_u32(p.M, d->Ho * d->Wo); p.mg_wo = gg_magic_u32(p.M, d->Wo);
 }
 
 static bool halo_try_dry(const ConvParams &p) { return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK; }
+
+extern "C" int gg_conv_runs_halo_tile(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    return gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK ? 1 : 0;
+}
 
 extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 {
     if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu) return 0;
     ConvParams p;
     fill_params(d, p);
-    if (gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK) return 1;
+    // halo-tile convs CAN always fuse it; the answer is whether they should (measured rule in gg_conv_halo.hip)
+    if (gg_conv_halo_try(p, (hipStream_t)-1) == GG_OK) return (GG_HALO_SEPARATE_NORM && d->path_hint == 0 && gg_conv_halo_prefers_separate_norm(p)) ? 0 : 1;
     if (gg_conv_box_try(p, (hipStream_t)-1) == GG_OK) return gg_conv_box_fuses_prologue(p) ? 1 : 0;
     // GroupNorm*SiLU inside the 160-step gather loop was measured slower (26 vs 16.6 us per conv: SiLU on the load -> LDS critical
     // path once per tap), so the gather kernels never fuse the prologue
@@ -747,6 +763,16 @@ extern "C" int gg_conv_fuses_prologue(const gg_conv_desc *d)
 
 bool gg_conv_box_emits_stats(const ConvParams &p);
 bool gg_conv_box_prologue_from_acc(const ConvParams &p);
+bool gg_conv_halo_fuses_posterior(const ConvParams &p);
+
+extern "C" int gg_conv_fuses_posterior(const gg_conv_desc *d)
+{
+    if (!d || d->C1 <= 0 || d->C1 % 32 || d->C2 % 32 || d->Cout_pad % 32 || d->epilogue_geglu || d->residual || d->out_dtype != GG_F32 || d->gn_acc ||
+        d->ddim_x || d->skip_C1) return 0;
+    ConvParams p;
+    fill_params(d, p);
+    return gg_conv_halo_fuses_posterior(p) ? 1 : 0;
+}
 
 extern "C" int gg_conv_prologue_from_acc(const gg_conv_desc *d)
 {
@@ -796,6 +822,17 @@ extern "C" int gg_conv_emits_stats(const gg_conv_desc *d)
     return (plan_gather5(p.M, p.C1, p.C2, p.Cout_pad, p.ntaps) == 1 && osp % 64 == 0) ? GG_ACC_STRIPES : 0;
 }
 
+#ifdef GG_EXP_WPREFETCH
+__global__ __launch_bounds__(256) void exp_wprefetch_kernel(const u32x4 *w, long long n16, unsigned *sink)
+{
+    unsigned a = 0;
+    if (n16 <= (3 << 20) / 16 * 1) {        // <= 3 MB: EVERY XCD (blockIdx & 7) reads all of it into its own L2
+        for (long long i = (long long)(blockIdx.x >> 3) * 256 + threadIdx.x; i < n16; i += 32 * 256) { const u32x4 v = w[i]; a ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+    } else
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 256 * 256) { const u32x4 v = w[i]; a ^= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+    if (a == 0x12345679u) sink[0] = a;      // practically never
+}
+#endif
 extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -807,7 +844,13 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
     if (d->stride != 1 && d->stride != 2) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: stride must be 1 or 2");
     if (d->upsample && d->stride != 1) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: upsample with stride");
     if (d->out_dtype != GG_BF16 && d->out_dtype != GG_F32) GG_FAIL(GG_ERR_BAD_DTYPE, "conv: out dtype");
-    if (!d->src1 || !d->weight || !d->out || (d->C2 && !d->src2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: null pointer");
+    if (!d->src1 || !d->weight || (!d->out && !d->post_xt) || (d->C2 && !d->src2)) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: null pointer");
+    if (d->post_xt) {
+        if (!gg_conv_fuses_posterior(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot run the fused CCDM reverse step (gg_conv_fuses_posterior)");
+        if (!d->post_labels_out || !d->post_scalars) GG_FAIL(GG_ERR_BAD_SHAPE, "conv: fused CCDM reverse step needs labels_out and scalars");
+        if (d->post_onehot_out && (d->post_onehot_stride < d->Cout || (d->post_onehot_stride & 1) || ((uintptr_t)d->post_onehot_out & 3)))
+            GG_FAIL(GG_ERR_BAD_SHAPE, "conv: fused CCDM reverse step: one-hot rows must be 4-byte aligned (even stride >= K)");
+    }
     const bool pro_acc = d->prologue_act && !d->gn_scale && !d->gn_shift && d->pro_acc1;
     if (pro_acc) {
         if (!gg_conv_prologue_from_acc(d)) GG_FAIL(GG_ERR_UNSUPPORTED, "conv: this shape cannot compute its GroupNorm prologue from accumulators (gg_conv_prologue_from_acc)");
@@ -851,6 +894,14 @@ extern "C" int gg_conv_forward(const gg_conv_desc *d, void *stream_)
             default: return launch_gather<1>(p, stream);
         }
     }
+#ifdef GG_EXP_WPREFETCH
+    // experiment (tools/experiments/README.md, "warm weights"): every conv preceded by a launch that reads its packed weights with the whole
+    // chip, so that the conv finds them in L2 / the memory-side cache -- bounds what a CONCURRENT weight prefetcher could buy
+    {
+        const long long wbytes = (long long)(p.Cout_pad / 32) * p.ntaps * p.nchunk * 2048;
+        hipLaunchKernelGGL(exp_wprefetch_kernel, dim3(256), dim3(256), 0, stream, (const u32x4 *)p.weight, wbytes >> 4, (unsigned *)d->out);
+    }
+#endif
 #ifdef GG_H3_STAMPS
     if (d->path_hint == 7 && d->workspace) p.ws = (float *)d->workspace;      // diagnostic build: phase stamps of the team halo kernel
 #endif

@@ -12,6 +12,7 @@
 // HBM/L2 traffic per block and chunk: one box (41 KB) instead of 27 gathered tiles (27 x 16 KB) in the generic kernel.
 #include <atomic>
 #include "gg_conv.h"
+#include "gg_posterior.h"
 #include <stdlib.h>
 #ifndef GG_HALO_G3
 #define GG_HALO_G3 1
@@ -39,7 +40,7 @@
 #define GG_HALO_WPS(NT) 2      /* measured: 4 waves/SIMD forces scratch spills (NT=2) and is not faster */
 #endif
 
-template <int D3, int NT, int UP, int HB>
+template <int D3, int NT, int UP, int HB, int POST = 0>
 __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), (GG_HALO_W16(D3, NT, HB) ? 4 : HB == 1 ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
     // HB 0: 512-position box 4x8x16 (2-D: 1x32x16); 1: 256 positions 4x4x16 (under-filled 3-D grids); 2: 1024 positions 8x8x16, one
@@ -272,6 +273,44 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
     // for the store's whole round trip.  With the bias / residual load of every tile behind the previous tile's store, the epilogue of
     // a 1024-position box took ~23 k cycles (half a chunk's taps; in-kernel stamps of the same pattern in gg_conv_halo3.hip: 25 k cycles
     // for 32 tiles).  So: the bias vectors and ALL residual pieces are loaded in front of the first store.
+    if constexpr (POST) {
+        // ===== fused CCDM reverse step (gg_conv_desc.post_xt): the logits never leave the CU =====
+        // The accumulator layout gives a lane 4 of a position's K <= 16 logits; through LDS (the box image is dead) every lane gets ALL
+        // logits of two of the wave's 16 TPW positions and runs gg_posterior.h on them: the very function of the stand-alone sampler kernel.
+        static_assert(NT == 1 && !GG_HALO_W16(D3, NT, HB) && (TPW * 16) % 64 == 0, "fused posterior: one 32-cout group, 64-lane position groups");
+        const f32x4 bv = brow ? *reinterpret_cast<const f32x4 *>(brow + g0 * 32 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float *scrp = reinterpret_cast<float *>(smem + 8192) + wave * (TPW * 16 * 16);        // [TPW * 16 positions][16 logits] fp32
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            f32x4 v = acc[tt][0];
+            if (brow) v += bv;
+            *reinterpret_cast<f32x4 *>(scrp + (tt * 16 + fr) * 16 + fq * 4) = v;
+        }
+        const float pa = p.post_scalars[0], pabar = p.post_scalars[1];
+        const long long poff = (p.post_draw && !p.post_E && p.post_offset_dev) ? p.post_offset_dev[0] : 0;
+#pragma unroll 1
+        for (int r = 0; r < TPW * 16 / 64; ++r) {
+            const int pp = r * 64 + lane, tt = pp >> 4, pw = pp & 15;
+            const int tile = wave * TPW + tt;
+            const int od = D3 ? tile / TH : 0, oh = D3 ? tile % TH : tile;
+            const long long m = (((long long)n * p.Do + (d0 + od)) * p.Ho + (h0 + oh)) * p.Wo + (w0 + pw);
+            const int x = p.post_xt[m];
+            float p0[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(scrp + pp * 16 + i * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p0[i * 4 + j] = q[j];
+            }
+            const float *erow = p.post_E ? p.post_E + m * p.Cout : nullptr;
+            int best;
+            if (p.Cout == 14) best = ccdm_posterior_voxel<16, 14>(p0, 1, x, pa, pabar, 14, m, p.post_draw, erow, (uint64_t)p.post_seed, poff, nullptr);
+            else best = ccdm_posterior_voxel<16>(p0, 1, x, pa, pabar, p.Cout, m, p.post_draw, erow, (uint64_t)p.post_seed, poff, nullptr);
+            p.post_labels_out[m] = best;
+            if (p.post_onehot_out) ccdm_onehot_row<16>(p.post_onehot_out + m * p.post_onehot_stride, best, p.Cout);
+        }
+        return;
+    }
     if constexpr (!GG_HALO_W16(D3, NT, HB)) {
         f32x4 bvec[2 * NT];
 #pragma unroll
@@ -457,7 +496,7 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
     }
 }
 
-template <int D3, int NT, int UP, int HB = 0>
+template <int D3, int NT, int UP, int HB = 0, int POST = 0>
 static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
     constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
@@ -470,13 +509,13 @@ static int launch_halo(const ConvParams &p, hipStream_t stream)
     if (hipGetDevice(&dev) != hipSuccess) return GG_ERR_HIP;
     const unsigned long long dev_bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_acquire) & dev_bit)) {
-        if (hipFuncSetAttribute((const void *)conv_halo_kernel<D3, NT, UP, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv_halo_kernel<D3, NT, UP, HB, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
             return GG_ERR_UNSUPPORTED;
         attr_mask.fetch_or(dev_bit, std::memory_order_release);
     }
     const int tiles_d = p.Do / TD, tiles_h = p.Ho / TH, tiles_w = p.Wo / TW;
     dim3 grid((unsigned)(p.N * tiles_d * tiles_h * tiles_w), (unsigned)(p.Cout_pad / (32 * NT)));
-    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB>), grid, dim3(GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), LDSB, stream, p, tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL((conv_halo_kernel<D3, NT, UP, HB, POST>), grid, dim3(GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), LDSB, stream, p, tiles_d, tiles_h, tiles_w);
     GG_CHECK_LAUNCH();
     return GG_OK;
 }
@@ -495,6 +534,58 @@ static int dispatch_nt(const ConvParams &p, int NT, hipStream_t stream)
 // team kernel for filled 3-D grids (gg_conv_halo3.hip); same contract
 int gg_conv_halo3_try(const ConvParams &p, hipStream_t stream);
 
+// widest cout tile (fewest re-stagings of the box) that still gives >= 256 workgroups; else the widest with >= 128.
+// 3-D: 27 taps per staged box, so filling the chip comes first (>= 256 workgroups, else >= 128).  2-D: only 9 taps per staged
+// box, staging dominates, so the widest cout tile that still gives 128 workgroups wins (AE 512->512 @128x128: NT 4 x 128
+// workgroups instead of NT 2 x 256)
+static int halo_pick_nt(bool d3, int G, long long tiles)
+{
+    for (int want : {!d3 ? 128 : 256, 128})
+        for (int cand : {4, 3, 2, 1})
+            if (G % cand == 0 && tiles * (G / cand) >= want) return cand;
+    return 1;
+}
+
+// Whether GroupNorm * SiLU in front of this conv is cheaper as its OWN pass than fused into the staging pass (the caller has checked
+// that gg_conv_halo_try takes the shape).  Fused, every staged element costs ~25 vector instructions incl. two transcendentals, once per
+// cout group and per box that holds it (halo redundancy 1.2x in 2-D, 2.1x for the 512-position 3-D boxes, 1.76x for the 1024-position
+// ones), in issue slots the MFMAs of the co-resident waves want; the separate pass is one HBM-bound read + write.  Measured on one box
+// (tools/experiments/probe_halo_2d_pro.py; fused vs prologue-free conv + apply pass, us):
+//   2-D 128->128 @512^2 112 vs 91 + 21 | 256->256 @256^2 96 vs 79 + 14 | 512->512 @128^2 136 vs 110 + 12 | 512->512 @64^2 59 vs 36 + 12
+//       96->96 @512^2 69 vs 60 + 17   | 192->192 @256^2 61 vs 53 + 15 | 384->384 @128^2 88 vs 69 + 12   | 384->384 @64^2 47 vs 30 + 12
+//   3-D 64->64 @128^3 477 vs 416 + 98 | 128->128 @64^3 222 vs 191 + 21 | 256->128 @64^3 398 vs 343 + 40 | 256->256 @32^3 156 vs 125 + 15
+//       512->256 @32^3 288 vs 236 + 13
+// => separate wherever the box is re-staged by >= 3 cout groups or by 2 groups of the 128-cout tile.  The one-group 3-D shapes (CCDM
+// 128 channels @64^3 / @32^3) look like wins above (-4 %), but IN the captured CCDM forward the rule applied to them lost: 15.47 -> 15.55 ms
+// (their apply pass reads a tensor the memory-side cache no longer holds); they stay fused.  With the rule as it is (captured, same box):
+// AE decode 3.51 -> 3.44 ms, cond-encode 1.458 -> 1.423 ms.
+bool gg_conv_halo_prefers_separate_norm(const ConvParams &p)
+{
+    const bool d3 = (p.kd == 3);
+    const int TD = d3 ? 4 : 1, TH = d3 ? 8 : 32, TW = 16;
+    const int G = p.Cout_pad / 32;
+    const long long tiles = (long long)p.N * (p.Do / TD) * (p.Ho / TH) * (p.Wo / TW);
+    const int NT = halo_pick_nt(d3, G, tiles);
+    const int groups = G / NT;
+    return groups >= 3 || (groups == 2 && NT == 4);
+}
+
+static bool halo_uses_1024_box(const ConvParams &p, bool d3, int NT, long long blocks)
+{
+    return d3 && NT <= 2 && !p.upsample && (p.Do % 8) == 0 && (p.path_hint == 6 || ((p.path_hint == 0 || p.path_hint == 8) && blocks >= 512));
+}
+
+// The CCDM reverse step as the epilogue of the head conv: the 1024-position 3-D box kernel with ONE 32-cout group holding all K <= 16 classes
+bool gg_conv_halo_fuses_posterior(const ConvParams &p)
+{
+    if (!(p.kd == 3 && p.kh == 3 && p.kw == 3) || p.stride != 1 || p.pad != 1 || p.upsample) return false;
+    if (p.Cout > 16 || p.Cout_pad != 32 || p.out_dtype != GG_F32 || p.residual || p.gn_acc) return false;
+    if (p.Wo % 16 || p.Ho % 8 || p.Do % 8) return false;
+    const long long tiles = (long long)p.N * (p.Do / 4) * (p.Ho / 8) * (p.Wo / 16);
+    if (p.path_hint != 6 && tiles < 128) return false;      // (the under-filled-grid gate of gg_conv_halo_try)
+    return halo_uses_1024_box(p, true, 1, tiles);
+}
+
 // Returns GG_ERR_UNSUPPORTED (silently, no error text) when the shape is outside the envelope: the caller then uses the
 // generic gather kernel.  stream == (hipStream_t)-1: dry run (only answers whether the halo kernel would be used).
 int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
@@ -508,7 +599,7 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
 #ifndef GG_HALO3_DEFAULT
 #define GG_HALO3_DEFAULT 0
 #endif
-    if (d3 && ((GG_HALO3_DEFAULT && p.path_hint == 0) || p.path_hint == 7)) {
+    if (d3 && !p.post_xt && ((GG_HALO3_DEFAULT && p.path_hint == 0) || p.path_hint == 7)) {
         const int rc3 = gg_conv_halo3_try(p, stream);
         if (rc3 != GG_ERR_UNSUPPORTED) return rc3;
     }
@@ -516,19 +607,8 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     if (p.Wo % TW || p.Ho % TH || p.Do % TD) return GG_ERR_UNSUPPORTED;
     const int G = p.Cout_pad / 32;
     const long long tiles = (long long)p.N * (p.Do / TD) * (p.Ho / TH) * (p.Wo / TW);
-    // widest cout tile (fewest re-stagings of the box) that still gives >= 256 workgroups; else the widest with >= 128
-    constexpr int max_nt = 4;
-    int NT = 0;
-    // 3-D: 27 taps per staged box, so filling the chip comes first (>= 256 workgroups, else >= 128).  2-D: only 9 taps per staged
-    // box, staging dominates, so the widest cout tile that still gives 128 workgroups wins (AE 512->512 @128x128: NT 4 x 128
-    // workgroups instead of NT 2 x 256)
     constexpr int wide2d = 1;
-    for (int want : {(!d3 && wide2d) ? 128 : 256, 128}) {
-        for (int cand : {4, 3, 2, 1})
-            if (cand <= max_nt && G % cand == 0 && tiles * (G / cand) >= want) { NT = cand; break; }
-        if (NT) break;
-    }
-    if (!NT) NT = 1;
+    const int NT = halo_pick_nt(d3, G, tiles);
     const long long blocks = tiles * (G / NT);
     // under-filled grids: the box / split-K gather paths are faster (2-D under one workgroup per CU: AE 512->512 @64x64 is 136 us
     // here at 128 workgroups); path_hint 1 / 4 / 6 (tests) lift the gate so that small shapes run on this kernel
@@ -543,10 +623,12 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
     // the halo redundancy drops from 2.1x to 1.76x, i.e. less staging (loads, GroupNorm*SiLU, LDS writes) per output.  Same-box A/B at
     // 128^3 with the fused prologue: 64->64 500 -> 468 us, 192->64 1338 -> 1240 us, 32->64 300 -> 280 us (bit-identical results);
     // 256->256 @32^3 would lose (177 vs 156 us: half the workgroups), hence the grid condition.  path_hint 6 (tests) forces it.
-    if (d3 && NT <= 2 && !p.upsample && (p.Do % 8) == 0 && (p.path_hint == 6 || ((p.path_hint == 0 || p.path_hint == 8) && blocks >= 512))) {
+    if (halo_uses_1024_box(p, d3, NT, blocks)) {
         if (NT == 2) return launch_halo<1, 2, 0, 2>(p, stream);
+        if (p.post_xt) return launch_halo<1, 1, 0, 2, 1>(p, stream);       // UNet head with the CCDM reverse step as its epilogue
         return launch_halo<1, 1, 0, 2>(p, stream);
     }
+    if (p.post_xt) return GG_ERR_UNSUPPORTED;      // (gg_conv_forward has asked gg_conv_fuses_posterior: not reached)
     if (d3 && NT <= 2 && (p.path_hint == 4 || ((p.path_hint == 0 || p.path_hint == 8) && blocks <= 256))) {
         if (NT == 2) return p.upsample ? launch_halo<1, 2, 1, 1>(p, stream) : launch_halo<1, 2, 0, 1>(p, stream);
         return p.upsample ? launch_halo<1, 1, 1, 1>(p, stream) : launch_halo<1, 1, 0, 1>(p, stream);

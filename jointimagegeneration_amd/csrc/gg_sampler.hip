@@ -1,31 +1,11 @@
 // Sampler-side kernels: CCDM fused posterior+sample, DDIM update, layout movers, small fp32 linears.
 #include "gg_common.h"
+#include "gg_posterior.h"
 
 // ------------------------------------------------------------------------------------------------------------
-// Philox4x32-10 (counter-based): counter = (voxel lo, voxel hi, draw index, step offset), key = seed.
+// CCDM reverse step, one voxel per thread (gg_posterior.h holds the arithmetic).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        uint32_t n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// CCDM reverse step, one voxel per thread. The arithmetic below is, expression for expression and in the same
-// left-to-right fp32 order (no FMA contraction, IEEE division), the C restatement oracle/ccdm_posterior.c, so the
-// labels agree bit-for-bit when probabilities (not logits) are fed.
-// ------------------------------------------------------------------------------------------------------------
-template <int KMAX>
+template <int KMAX, int KS = 0>
 __global__ __launch_bounds__(256) void ccdm_posterior_kernel(const float *__restrict__ head, int head_stride, int is_logits,
                                                              const int *__restrict__ xt, const float *__restrict__ E,
                                                              uint64_t seed, const long long *__restrict__ offset_dev, int draw,
@@ -33,106 +13,17 @@ __global__ __launch_bounds__(256) void ccdm_posterior_kernel(const float *__rest
                                                              int *__restrict__ labels_out, float *__restrict__ probs_out,
                                                              bf16_t *__restrict__ onehot_out, int onehot_stride)
 {
-#pragma clang fp contract(off)
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const float a = scalars[0], abar = scalars[1];
-    const float Kf = (float)K;
-    const float u = (1.0f - a) / Kf;
-    const float v = (1.0f - abar) / Kf;
-    const float bd = abar * 1.0f + v;
-    const float bo = abar * 0.0f + v;
-    const int x = xt[m];
-
-    float p0[KMAX], A[KMAX], out[KMAX];
-    {
-        const float *hp = head + m * head_stride;
+    float p0[KMAX];
+    const float *hp = head + m * head_stride;
 #pragma unroll
-        for (int c = 0; c < KMAX; ++c) p0[c] = (c < K) ? hp[c] : 0.f;
-        if (is_logits) {   // nn.Softmax(dim=1) of the UNet head, fp32
-            float mx = p0[0];
-#pragma unroll
-            for (int c = 1; c < KMAX; ++c) if (c < K) mx = fmaxf(mx, p0[c]);
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) if (c < K) { p0[c] = expf(p0[c] - mx); s = s + p0[c]; }
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) if (c < K) p0[c] = p0[c] / s;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) {
-        A[c] = a * (c == x ? 1.0f : 0.0f) + u;
-        out[c] = 0.f;
-    }
-#pragma unroll
-    for (int d = 0; d < KMAX; ++d) {
-        if (d < K) {
-            float den = 0.f;
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) if (c < K) den = den + A[c] * (c == d ? bd : bo);
-            const float pd = p0[d];
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) if (c < K) {
-                const float post = (A[c] * (c == d ? bd : bo)) / den;
-                out[c] = out[c] + post * pd;
-            }
-        }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) if (c < K) {
-        if (out[c] < 1e-12f) out[c] = 1e-12f;
-        s = s + out[c];
-    }
-    // exponential race
-    float Ev[KMAX];
-    const bool use_race = draw != 0;
-    if (use_race) {
-        if (E) {
-#pragma unroll
-            for (int c = 0; c < KMAX; ++c) Ev[c] = (c < K) ? E[m * K + c] : 1.f;
-        } else {
-            const long long off = offset_dev ? offset_dev[0] : 0;
-#pragma unroll
-            for (int q4 = 0; q4 < KMAX / 4; ++q4) {
-                uint32_t ctr[4] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)q4, (uint32_t)off};
-                philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float uu = (float)((ctr[j] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
-                    Ev[q4 * 4 + j] = -__logf(uu) + 1e-30f;
-                }
-            }
-        }
-    }
-    int best = 0;
-    float bestv = -1.0f;
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) if (c < K) {
-        const float pn = out[c] / s;
-        const float r = use_race ? pn / Ev[c] : pn;
-        if (probs_out) probs_out[m * K + c] = pn;
-        if (r > bestv) { bestv = r; best = c; }
-    }
+    for (int c = 0; c < KMAX; ++c) p0[c] = (c < (KS > 0 ? KS : K)) ? hp[c] : 0.f;
+    const long long off = (draw && !E && offset_dev) ? offset_dev[0] : 0;
+    const int best = ccdm_posterior_voxel<KMAX, KS>(p0, is_logits, xt[m], scalars[0], scalars[1], K, m, draw, E ? E + m * K : nullptr, seed, off,
+                                                probs_out ? probs_out + m * K : nullptr);
     labels_out[m] = best;
-    if (onehot_out) {
-        // channels [0, K) of the voxel's row as 4-byte pairs (+ one 2-byte tail for odd K): 7 stores instead of 14 two-byte ones at K = 14
-        // (two-byte stores cost ~12x a 16-byte store per byte on this memory system, MI355X_MICROARCH.md); channel K and beyond (the
-        // condition image, the padding lanes) are NOT touched
-        bf16_t *oh = onehot_out + m * onehot_stride;
-#pragma unroll
-        for (int c = 0; c + 1 < KMAX; c += 2) {
-            if (c + 1 < K) {
-                bf16x2 pr;
-                pr[0] = (bf16_t)(c == best ? 1.0f : 0.0f);
-                pr[1] = (bf16_t)(c + 1 == best ? 1.0f : 0.0f);
-                *reinterpret_cast<bf16x2 *>(oh + c) = pr;
-            } else if (c < K) {
-                oh[c] = (bf16_t)(c == best ? 1.0f : 0.0f);
-            }
-        }
-    }
+    if (onehot_out) ccdm_onehot_row<KMAX, KS>(onehot_out + m * onehot_stride, best, K);
 }
 
 extern "C" int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, int32_t head_is_logits, const int32_t *xt,
@@ -148,7 +39,11 @@ extern "C" int gg_ccdm_posterior_sample(const float *head, int32_t head_stride, 
     if (onehot_out && ((onehot_stride & 1) || ((uintptr_t)onehot_out & 3))) GG_FAIL(GG_ERR_BAD_SHAPE, "ccdm_posterior_sample: onehot rows must be 4-byte aligned (even stride)");
     if (M <= 0) return GG_OK;
     dim3 grid((unsigned)((M + 255) / 256));
-    if (K <= 16)
+    if (K == 14)        // the class count of the shipped configs (13 organs + background), compiled in
+        hipLaunchKernelGGL((ccdm_posterior_kernel<16, 14>), grid, dim3(256), 0, stream, head, head_stride, head_is_logits, xt, E,
+                           philox_seed, (const long long *)philox_offset_dev, draw, scalars_dev, K, (long long)M, labels_out,
+                           probs_out, (bf16_t *)onehot_out, onehot_stride);
+    else if (K <= 16)
         hipLaunchKernelGGL(ccdm_posterior_kernel<16>, grid, dim3(256), 0, stream, head, head_stride, head_is_logits, xt, E,
                            philox_seed, (const long long *)philox_offset_dev, draw, scalars_dev, K, (long long)M, labels_out,
                            probs_out, (bf16_t *)onehot_out, onehot_stride);

@@ -105,6 +105,7 @@ class CL:
     C: int
     acc: Optional[torch.Tensor] = None      # int64 [N, stripes, Cpad, 2]: striped fixed-point per-channel (sum, sumsq) left by the producing conv
     fused_ddim: bool = False                # the producing (head) conv already applied the DDIM update (gg_conv_desc.ddim_x)
+    fused_post: bool = False                # the producing (head) conv already ran the CCDM reverse step (gg_conv_desc.post_xt)
 
     @property
     def N(self): return self.t.shape[0]
@@ -245,9 +246,32 @@ def conv_fuses_skip(src1: CL, cout: int, skip1: CL, skip2: Optional[CL] = None, 
     return bool(lib.gg_conv_fuses_skip(C.byref(d)))
 
 
+def _shape_desc(src1: CL, cout: int, k, stride: int, pad: int, upsample: bool, src2: Optional[CL]) -> "ConvDesc":
+    N, D, H, W, C1 = src1.t.shape
+    Do, Ho, Wo = conv_out_extent((D, H, W), k, stride, pad, upsample)
+    d = ConvDesc()
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = C1, (src2.t.shape[-1] if src2 is not None else 0)
+    d.Cout, d.Cout_pad = cout, pad32(cout)
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    d.Do, d.Ho, d.Wo = Do, Ho, Wo
+    d.path_hint = PATH_HINT
+    return d
+
+
+def conv_runs_halo_tile(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
+                        src2: Optional[CL] = None, **_ignored) -> bool:
+    """True if gg_conv_forward runs this shape on the halo-tile kernel."""
+    if is_f32(src1.t):
+        return False
+    return bool(_lib.load().gg_conv_runs_halo_tile(C.byref(_shape_desc(src1, cout, k, stride, pad, upsample, src2))))
+
+
 def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: int = 1, upsample: bool = False,
                         src2: Optional[CL] = None, **_ignored) -> bool:
-    """True if this conv runs on the halo-tile kernel (GroupNorm prologue applied once per element while staging)."""
+    """True if the GroupNorm (* SiLU) in front of this conv should be handed to the conv as its prologue (applied once per element while
+    staging); False: a separate apply pass + the prologue-free conv is faster (gg_conv_fuses_prologue, measured rule in gg_conv_halo.hip)."""
     if is_f32(src1.t):
         return False
     lib = _lib.load()
@@ -269,6 +293,11 @@ def conv_fuses_prologue(src1: CL, cout: int, k=(1, 3, 3), stride: int = 1, pad: 
 GN_ACC = True
 TINY_IMAGE_POSITIONS = 0            # > 0: outputs with at most this many positions per sample also leave their sums, so that the next SiLU norm is folded into
                                     # its conv (16 = the 4x4 level: measured SLOWER, 1558 vs 1548 us per latent-UNet forward: producer epilogues + transform > launch)
+# CCDM reverse step as the head conv's epilogue (gg_conv_desc.post_xt) where gg_conv_fuses_posterior says so (the 128^3 head).  Bit-identical
+# to the two-launch form (tests).  What it buys is the 0.27 GB logit round trip only: the reverse step itself is ~3 k dependent vector
+# instructions per voxel (IEEE divisions, Philox, exp) and VALU-bound wherever it runs -- rocprofv3, captured steps @128^3: head conv with the
+# epilogue 523 us vs head conv 327 + sampler kernel 210 us (tools/experiments/probe_ccdm_step.py).  A/B switch.
+FUSE_POSTERIOR = True
 PROLOGUE_FROM_ACC = True            # box convs fold their producers' accumulators themselves where gg_conv_prologue_from_acc says so (A/B switch)
 GN_ACC_MAX_ELEMS = 1 << 21          # per sample: only tensors whose norm is launch-bound (latent UNet at batch 1)
 GN_ACC_MIN_ELEMS = 1 << 17          # below this the one-launch GroupNorm kernels are as fast (probe_gn_acc_min.py: 2^18 1593, 2^17 1586, 2^16 1590, 2^15 1604 us per forward)
@@ -320,12 +349,15 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
          upsample: bool = False, src2: Optional[CL] = None, residual: Optional[CL] = None, out_f32: bool = False,
          bias_per_sample: bool = False, prologue: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, prologue_silu: bool = True,
          out: Optional[torch.Tensor] = None, ddim: Optional[tuple] = None, geglu: bool = False, prologue_acc: Optional[tuple] = None,
-         want_stats: bool = False, skip: Optional[tuple] = None) -> CL:
+         want_stats: bool = False, skip: Optional[tuple] = None, post: Optional[dict] = None) -> CL:
     """skip = (x1: CL, x2: CL or None, packed 1x1 weight): K-concatenated skip projection (conv_fuses_skip; `bias` must include its bias);
     prologue_acc = (gamma, beta, eps): GroupNorm prologue computed inside the conv from src1.acc / src2.acc (conv_prologue_from_acc);
     want_stats: leave the output's GroupNorm sums behind whatever its size (the consumer will fold them itself);
     ddim = (x fp32 [M,4], scalars fp32[4] on device, pred_x0 fp32 [M,4] or None, unet_in bf16 [M, stride] or None): the DDIM update
-    runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step."""
+    runs as this (head) conv's epilogue when the kernel supports it (CL.fused_ddim tells); otherwise the caller launches gg_ddim_step;
+    post = dict(xt, scalars, K, E, philox_seed, philox_offset, draw, labels_out, onehot_out): the CCDM reverse step (the arguments of
+    ccdm_posterior_sample) as this (head) conv's epilogue where gg_conv_fuses_posterior says so (CL.fused_post tells; `out` is then not
+    written); otherwise the caller launches gg_ccdm_posterior_sample on the logits."""
     lib = _lib.load()
     t1 = src1.t
     N, D, H, W, C1 = t1.shape
@@ -407,8 +439,18 @@ def conv(src1: CL, weight: torch.Tensor, bias: Optional[torch.Tensor], cout: int
         d.ddim_unet_in = _ptr(uin)
         d.ddim_unet_in_stride = uin.shape[-1] if uin is not None else 0
         fused = True
+    fused_post = False
+    if post is not None and FUSE_POSTERIOR and acc is None and post["K"] == cout and lib.gg_conv_fuses_posterior(C.byref(d)):
+        oh = post.get("onehot_out")
+        d.post_xt, d.post_labels_out, d.post_scalars = post["xt"].data_ptr(), post["labels_out"].data_ptr(), post["scalars"].data_ptr()
+        d.post_E = _ptr(post.get("E"))
+        d.post_philox_seed = int(post.get("philox_seed", 0))
+        d.post_philox_offset_dev = _ptr(post.get("philox_offset"))
+        d.post_draw = 1 if post.get("draw", True) else 0
+        d.post_onehot_out, d.post_onehot_stride = _ptr(oh), (oh.shape[-1] if oh is not None else 0)
+        fused_post = True
     check(lib.gg_conv_forward(C.byref(d), _stream()), "gg_conv_forward")
-    return CL(out, cout // 2 if geglu else cout, acc=acc, fused_ddim=fused)
+    return CL(out, cout // 2 if geglu else cout, acc=acc, fused_ddim=fused, fused_post=fused_post)
 
 
 # ----------------------------------------------------------------------------------------------- norms / elementwise

@@ -107,7 +107,7 @@ class _UNetBase(nn.Module):
 
     # ---- channels-last execution ---------------------------------------------------------------------------------
     def forward_cl(self, x: CL, bias_row: torch.Tensor, context: Optional[CL] = None, head_out: Optional[torch.Tensor] = None,
-                   head_ddim: Optional[tuple] = None) -> CL:
+                   head_ddim: Optional[tuple] = None, head_post: Optional[dict] = None) -> CL:
         """x: CL bf16 network input (already concatenated/padded); bias_row: flat fp32 from time_bias_*.
         Returns the head output as fp32 CL [N, D, H, W, pad32(out_channels)] (logits for CCDM, eps for LDM)."""
         N = x.N
@@ -130,6 +130,8 @@ class _UNetBase(nn.Module):
             conv = self.out[2]
             pw, pb = packed_conv(conv, h.Cpad)
             extra = {"ddim": head_ddim} if head_ddim is not None else {}     # DDIM update as the head conv's epilogue (ddim.py:190-204)
+            if head_post is not None:
+                extra["post"] = head_post                                    # CCDM reverse step as the head conv's epilogue
             return norm_conv(h, self.out[0], True, pw, pb, conv.weight.shape[0], k=_k3(conv.weight), out_f32=True, out=head_out, **extra)
         finally:
             ops.stats_end(x.t.device)

@@ -236,7 +236,7 @@ def test_c3_full_ccdm_128_forward_vs_oracle(dev):
     x = S.one_hot_bchw(lab, K)
     cond = torch.zeros(1, 1, R, R, R)
     xin = ops.to_cl(x.to(dev), c_pad=32)
-    assert ops.conv_fuses_prologue(ops.CL(torch.empty(1, R, R, R, 64, dtype=torch.bfloat16, device=dev), 64), 64, k=(3, 3, 3))
+    assert ops.conv_runs_halo_tile(ops.CL(torch.empty(1, R, R, R, 64, dtype=torch.bfloat16, device=dev), 64), 64, k=(3, 3, 3))
     got = model.unet(x.to(dev), cond.to(dev), None, torch.tensor([117.0], device=dev))["diffusion_out"].cpu()
     torch.set_num_threads(cores())
     ref = O.unet_forward(sd, torch.cat([x, cond], 1), torch.tensor([117.0]), model_channels=64, head_channels=32, softmax_out=True)
@@ -273,6 +273,15 @@ def test_c3_ccdm_128_captured_steps_equal_eager_steps(dev):
     print(f"C3 @128^3, {steps} reverse steps: graph vs eager label mismatches {int((lab_g != lab_e).sum())} of {lab_g.numel()}; {moved:.3f} of the voxels changed label")
     assert torch.equal(lab_g, lab_e)
     assert moved > 0.05                              # the chain really sampled
+    # the reverse step as the head conv's epilogue (default at this size) against the two-launch form (fp32 logits, then the sampler kernel)
+    from jointimagegeneration_amd import ops
+    assert ops.FUSE_POSTERIOR
+    ops.FUSE_POSTERIOR = False
+    try:
+        lab_2, _ = model.sample_labels(x_T, cond, 10000 + steps)
+    finally:
+        ops.FUSE_POSTERIOR = True
+    assert torch.equal(lab_e, lab_2)
 
 
 def test_ccdm_batch_elements_are_independent_64x128x128(dev):

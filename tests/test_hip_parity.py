@@ -100,7 +100,7 @@ def test_conv_halo_kernel_matches_oracle(dev, case, halo_hint):
     """Same oracle, but shapes inside the halo-tile kernel's envelope (path_hint = 1 lifts the grid-fill gate)."""
     from jointimagegeneration_amd import ops
     name, dims, N, Cin, Cout, sp, up = case
-    assert ops.conv_fuses_prologue(ops.CL(torch.empty((N,) + (1,) * (3 - dims) + sp + (ops.pad32(Cin),), dtype=torch.bfloat16, device=dev), Cin),
+    assert ops.conv_runs_halo_tile(ops.CL(torch.empty((N,) + (1,) * (3 - dims) + sp + (ops.pad32(Cin),), dtype=torch.bfloat16, device=dev), Cin),
                                    Cout, k=(1,) * (3 - dims) + (3,) * dims, upsample=up)        # really the halo kernel
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn((N, Cin) + sp, generator=g)
@@ -1046,7 +1046,7 @@ def test_full_size_conv3d_properties(dev):
     x = torch.randn(1, S, S, S, 64, generator=g, device=dev).bfloat16()
     w = (torch.randn(64, 64, 3, 3, 3, generator=g, device=dev) / math.sqrt(64 * 27))
     pw = ops.pack_conv_weight(w, 64)
-    assert ops.conv_fuses_prologue(ops.CL(x, 64), 64, k=(3, 3, 3))            # this shape runs on the halo-tile kernel
+    assert ops.conv_runs_halo_tile(ops.CL(x, 64), 64, k=(3, 3, 3))            # this shape runs on the halo-tile kernel
     y = ops.conv(ops.CL(x, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
     y2 = ops.conv(ops.CL(x, 64), pw, None, 64, k=(3, 3, 3), out_f32=True).t
     assert torch.equal(y, y2)                                                   # repeatable bit for bit
@@ -1346,3 +1346,61 @@ def test_stats_arena_is_replay_safe_when_a_forward_is_captured_cold(dev):
     assert int(want.abs().sum()) != 0
     for i, s_ in enumerate(sums):
         assert torch.equal(s_, want), f"replay {i}: GroupNorm sums differ from the eager launch (stale accumulators folded in)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["philox", "tape", "argmax"])
+def test_head_conv_with_fused_ccdm_reverse_step_equals_conv_then_sampler_kernel(dev, monkeypatch, mode):
+    """gg_conv_desc.post_xt: softmax + posterior + draw as the epilogue of the UNet head conv (1024-position 3-D halo box) must give,
+    bit for bit, the labels and one-hot rows of the two-launch form (fp32 logits, then gg_ccdm_posterior_sample): both run
+    gg_posterior.h on the same fp32 accumulator + bias.  Reference semantics: ccdm/ddpm/models/diffusion_model (posterior), pinned against
+    the oracle by the sampler-kernel tests above."""
+    from jointimagegeneration_amd import ops
+    monkeypatch.setattr(ops, "PATH_HINT", 6)                 # the 1024-position box on a small grid
+    K, Cin, sp = 14, 64, (16, 16, 32)
+    M = sp[0] * sp[1] * sp[2]
+    g = torch.Generator().manual_seed(77)
+    x = ops.CL(torch.randn((1,) + sp + (Cin,), generator=g).to(dev).bfloat16(), Cin)
+    w = (torch.randn(K, Cin, 3, 3, 3, generator=g) * (3.0 / math.sqrt(Cin * 27))).to(dev)      # logits spread over a few units
+    pw = ops.pack_conv_weight(w, Cin)
+    bias = torch.zeros(1, 32, device=dev); bias[0, :K] = torch.randn(K, generator=g).to(dev) * 0.3
+    gamma, beta = (1 + 0.1 * torch.randn(Cin, generator=g)).to(dev), (0.1 * torch.randn(Cin, generator=g)).to(dev)
+    prol = ops.groupnorm_stats(x, gamma, beta, 1e-5)
+    xt = torch.randint(0, K, (M,), generator=g, dtype=torch.int32).to(dev)
+    scal = torch.tensor([0.97, 0.41], dtype=torch.float32, device=dev)
+    E = (-torch.log(torch.rand(M, K, generator=g).clamp_min(1e-7))).to(dev) if mode == "tape" else None
+    off = torch.tensor([123], dtype=torch.int64, device=dev)
+    draw = mode != "argmax"
+    kw = dict(k=(3, 3, 3), out_f32=True, prologue=prol, bias_per_sample=True)
+
+    logits = ops.conv(x, pw, bias, K, **kw).t
+    lab_a = torch.empty(M, dtype=torch.int32, device=dev)
+    oh_a = torch.full((M, 32), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.ccdm_posterior_sample(logits.view(M, -1), True, xt, scal, K, E=E, philox_seed=991, philox_offset=off, draw=draw, labels_out=lab_a, onehot_out=oh_a)
+
+    lab_b = xt.clone()                                        # in place, as the sampler loop uses it (labels_out aliases xt)
+    oh_b = torch.full((M, 32), 7.0, dtype=torch.bfloat16, device=dev)
+    sentinel = torch.full_like(logits, -3.0)
+    y = ops.conv(x, pw, bias, K, out=sentinel, post=dict(xt=lab_b, scalars=scal, K=K, E=E, philox_seed=991, philox_offset=off, draw=draw,
+                                                        labels_out=lab_b, onehot_out=oh_b), **kw)
+    assert y.fused_post                                       # really the fused epilogue
+    assert torch.equal(sentinel, torch.full_like(logits, -3.0))          # the logits are NOT written in this mode
+    assert torch.equal(lab_a, lab_b)
+    assert torch.equal(oh_a, oh_b)
+    assert torch.equal(oh_b[:, K:], torch.full((M, 32 - K), 7.0, dtype=torch.bfloat16, device=dev))      # channels >= K untouched
+    assert len(torch.unique(lab_b)) >= 4                      # a non-trivial label field
+    if draw:
+        assert (lab_b != xt).float().mean() > 0.02
+
+
+@pytest.mark.gpu
+def test_fused_ccdm_reverse_step_is_refused_outside_its_envelope(dev):
+    from jointimagegeneration_amd import ops
+    K, Cin, sp = 14, 32, (8, 8, 16)                          # production dispatch: this grid runs on the box / gather kernels
+    M = sp[0] * sp[1] * sp[2]
+    x = ops.CL(torch.randn((1,) + sp + (Cin,), device=dev).bfloat16(), Cin)
+    pw = ops.pack_conv_weight(torch.randn(K, Cin, 3, 3, 3, device=dev) * 0.05, Cin)
+    xt = torch.zeros(M, dtype=torch.int32, device=dev)
+    y = ops.conv(x, pw, None, K, k=(3, 3, 3), out_f32=True,
+                 post=dict(xt=xt, scalars=torch.tensor([0.9, 0.5], device=dev), K=K, labels_out=xt, draw=False))
+    assert not y.fused_post and torch.isfinite(y.t).all()    # plain conv: the caller launches the sampler kernel itself

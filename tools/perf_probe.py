@@ -2,6 +2,9 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("H3_LIB"):      # same-box A/B: a variant library from tools/experiments/ab/
+    from jointimagegeneration_amd import _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments", "ab", os.environ["H3_LIB"])
 from jointimagegeneration_amd import ops
 from jointimagegeneration_amd.ops import CL, pad32
 from jointimagegeneration_amd.synth import randomize_parameters
@@ -14,9 +17,21 @@ which = sys.argv[1:] or ["ccdm64", "ldm", "ae"]
 
 def timeit(fn, n=3, warm=1):
     for _ in range(warm): fn()
-    torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.time() - t0) / n
+    best = 1e9
+    for _ in range(int(os.environ.get("GG_PROBE_ROUNDS", "1"))):      # same-box A/B runs: best of several rounds
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(n): fn()
+        torch.cuda.synchronize(); best = min(best, (time.time() - t0) / n)
+    return best
+
+def graph_time(fn) -> str:
+    if not os.environ.get("GG_PROBE_GRAPH"):
+        return ""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return f", graph {timeit(lambda: g.replay(), n=5)*1e3:.3f} ms"
+
 
 for w in which:
     if w.startswith("ccdm"):
@@ -30,7 +45,14 @@ for w in which:
         row = u.time_bias_rows(torch.tensor([17.0], device=dev))
         t = timeit(lambda: u.forward_cl(x, row), n=2)
         gf = 12720.7 * (R / 128) ** 3
-        print(f"CCDM UNet {R}^3 forward: {t*1e3:.1f} ms  ({gf/t/1e3:.1f} TFLOP/s)")
+        msg = f"CCDM UNet {R}^3 forward: {t*1e3:.2f} ms  ({gf/t/1e3:.1f} TFLOP/s)"
+        if os.environ.get("GG_PROBE_GRAPH"):       # + the captured forward (what the sampler's captured step replays)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                u.forward_cl(x, row)
+            tg = timeit(lambda: g.replay(), n=4)
+            msg += f", graph {tg*1e3:.2f} ms"
+        print(msg)
     elif w == "ldm":
         u = UNetModel(dims=2, image_size=512, in_channels=8, out_channels=4, model_channels=160, attention_resolutions=[8, 4, 2],
                       num_res_blocks=2, channel_mult=[1, 2, 4, 4, 5], num_head_channels=32).eval()
@@ -56,8 +78,9 @@ for w in which:
             if gfd:
                 z = CL(torch.randn(1, 1, 64, 64, 32, device=dev).bfloat16(), 4)
                 t = timeit(lambda: a.decode_cl(z), n=3)
-                print(f"AE decode 64^2->512^2: {t*1e3:.1f} ms ({gfd/t/1e3:.1f} TFLOP/s)")
+                print(f"AE decode 64^2->512^2: {t*1e3:.3f} ms ({gfd/t/1e3:.1f} TFLOP/s)" + graph_time(lambda: a.decode_cl(z)))
             if gfe:
                 x = CL(torch.randn(1, 1, 512, 512, 32, device=dev).bfloat16(), 2)
                 t = timeit(lambda: a.encode_moments_cl(x), n=3)
-                print(f"AE cond-encode 512^2->64^2: {t*1e3:.1f} ms ({gfe/t/1e3:.1f} TFLOP/s)")
+                gt = graph_time(lambda: a.encode_moments_cl(x))
+                print(f"AE cond-encode 512^2->64^2: {t*1e3:.3f} ms ({gfe/t/1e3:.1f} TFLOP/s)" + gt)
