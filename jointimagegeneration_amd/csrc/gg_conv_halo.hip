@@ -245,7 +245,7 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
                         xf[tt] = *reinterpret_cast<const bf16x8 *>(xs + (hd * HH + hh) * (HW * 64) + lane_off[kw]);
                     }
 #pragma unroll
-                    for (int ct = 0; ct < 2 * NT; ++ct) {
+                    for (int ct = 0; ct < (POST ? 1 : 2 * NT); ++ct) {      // POST: K <= 16 classes = the first 16-cout tile only
                         const int r = ct * 16 + fr;
                         const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wb + r * 64 + swz64(r, fq) * 16);   // image pre-swizzled at pack time
 #pragma unroll
@@ -540,6 +540,8 @@ int gg_conv_halo3_try(const ConvParams &p, hipStream_t stream);
 // workgroups instead of NT 2 x 256)
 static int halo_pick_nt(bool d3, int G, long long tiles)
 {
+    // (3-D grids that only fill the chip with one 32-cout group per workgroup -- 128 couts @32^3: 64 tiles x 4 groups -- on two groups
+    // per 256-position box instead, the same 256 workgroups: captured CCDM forward 15.40 -> 15.53 ms, not kept)
     for (int want : {!d3 ? 128 : 256, 128})
         for (int cand : {4, 3, 2, 1})
             if (G % cand == 0 && tiles * (G / cand) >= want) return cand;
