@@ -19,7 +19,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 tools/perf_probe.py ccdm128 > /dev/null 2>&1
 python3 tools/pmc_parse.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_conv3d.json
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq_ccdm -- python3 tools/perf_probe.py ccdm128 > /dev/null 2>&1
-{ echo "## conv_halo_kernel<1, 2, 0, 2> in python3 tools/perf_probe.py ccdm128"; python3 tools/pmc_sq.py "conv_halo_kernel<1, 2, 0, 2>" $OUT/pmc_sq_ccdm; } > $OUT/pmc_sq_summary.txt
+{ echo "## conv_halo_kernel<1, 2, 0, 2, 0> in python3 tools/perf_probe.py ccdm128"; python3 tools/pmc_sq.py "conv_halo_kernel<1, 2, 0, 2" $OUT/pmc_sq_ccdm; } > $OUT/pmc_sq_summary.txt
 echo "ccdm passes done"
 # 4. AE decode + cond-encode @512^2: kernel stats, FETCH / WRITE / SQ for the 2-D halo conv and the single-head attention
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ae -o ae -- python3 tools/perf_probe.py ae > $OUT/ae_probe.log 2>&1
