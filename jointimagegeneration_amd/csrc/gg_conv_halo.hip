@@ -20,6 +20,9 @@
 #ifndef GG_HALO_G3_2D
 #define GG_HALO_G3_2D 1        /* the same for the 2-D kernel at NT >= 3 (AE convs; same-box A/B: decode 4.137 -> 4.05 ms, cond-encode 1.79 -> 1.75 ms) */
 #endif
+#ifndef GG_HALO_G3_HB1
+#define GG_HALO_G3_HB1 1      /* three taps per barrier on the 256-position 3-D boxes too: 53 KiB of LDS, still three workgroups per CU; captured CCDM forward 15.45 -> 14.94 ms (A/B switch) */
+#endif
 #ifndef GG_HALO_TSTORE
 #define GG_HALO_TSTORE 1       /* epilogue stores and residual loads transposed through LDS into full-line runs (0: straight in the accumulator layout) */
 #endif
@@ -69,7 +72,7 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
     // 9 instead of 27 barriers per chunk (same-box A/B, CCDM forward @128^3: 16.54 -> 16.42 ms).  Hand-ordered software pipelines of the
     // tap loop on top of it (fragments of tap s+1 requested under the MFMAs of tap s; one or two register sets; immediate-offset
     // addressing) were NOT faster: 21.6 / 16.75 / 18.7 ms, see tools/experiments/README.md and gg_conv_halo_tap_pipeline.hip.txt.
-    constexpr bool G3 = (GG_HALO_G3 && D3 && (HB == 2 || NT >= 3)) || (GG_HALO_G3_2D && !D3 && NT >= 3);
+    constexpr bool G3 = (GG_HALO_G3 && D3 && (HB == 2 || (GG_HALO_G3_HB1 && HB == 1) || NT >= 3)) || (GG_HALO_G3_2D && !D3 && NT >= 3);
     constexpr int GSZ = G3 ? 3 : 1;                      // taps per weight slot
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // XBYTES + 2 * GSZ * WBYTES (launch_halo)
     char *xs = smem;
@@ -501,7 +504,7 @@ static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
     constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
     constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1, HH = UP ? TH / 2 + 2 : TH + 2, HW = UP ? TW / 2 + 2 : TW + 2;
-    constexpr bool G3 = (GG_HALO_G3 && D3 && (HB == 2 || NT >= 3)) || (GG_HALO_G3_2D && !D3 && NT >= 3);
+    constexpr bool G3 = (GG_HALO_G3 && D3 && (HB == 2 || (GG_HALO_G3_HB1 && HB == 1) || NT >= 3)) || (GG_HALO_G3_2D && !D3 && NT >= 3);
     constexpr int LDSB = ((HD * HH * HW * 64 + 1023) / 1024) * 1024 + (G3 ? 6 : 2) * NT * 2048;
     // the attribute is per device: one bit per device ordinal (setting it twice from two threads is harmless)
     static std::atomic<unsigned long long> attr_mask{0};
