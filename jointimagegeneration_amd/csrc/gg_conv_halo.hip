@@ -20,6 +20,9 @@
 #ifndef GG_HALO_G3_2D
 #define GG_HALO_G3_2D 1        /* the same for the 2-D kernel at NT >= 3 (AE convs; same-box A/B: decode 4.137 -> 4.05 ms, cond-encode 1.79 -> 1.75 ms) */
 #endif
+#ifndef GG_HALO_2D_HB1
+#define GG_HALO_2D_HB1 1       /* 256-position boxes for under-filled 2-D grids at NT >= 3 (A/B switch) */
+#endif
 #ifndef GG_HALO_G3_HB1
 #define GG_HALO_G3_HB1 1      /* three taps per barrier on the 256-position 3-D boxes too: 53 KiB of LDS, still three workgroups per CU; captured CCDM forward 15.45 -> 14.94 ms (A/B switch) */
 #endif
@@ -32,7 +35,7 @@
 #ifndef GG_HALO_W16_3D
 #define GG_HALO_W16_3D 0
 #endif
-#define GG_HALO_W16(D3, NT, HB) ((GG_HALO_W16_2D && !(D3) && (NT) >= 3) || (GG_HALO_W16_3D && (D3) && ((HB) == 2 || (NT) >= 3)))
+#define GG_HALO_W16(D3, NT, HB) ((GG_HALO_W16_2D && !(D3) && (NT) >= 3 && (HB) != 1) || (GG_HALO_W16_3D && (D3) && ((HB) == 2 || (NT) >= 3)))
 #ifndef GG_HALO_DMA_UPPER
 #define GG_HALO_DMA_UPPER 0
 #endif
@@ -44,11 +47,13 @@
 #endif
 
 template <int D3, int NT, int UP, int HB, int POST = 0>
-__global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), (GG_HALO_W16(D3, NT, HB) ? 4 : HB == 1 ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
+__global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB != 2) ? 256 : 512), (GG_HALO_W16(D3, NT, HB) ? 4 : (HB == 1 && D3) ? 3 : 2)) void conv_halo_kernel(const ConvParams p, const int tiles_d, const int tiles_h, const int tiles_w)
 {
     // HB 0: 512-position box 4x8x16 (2-D: 1x32x16); 1: 256 positions 4x4x16 (under-filled 3-D grids); 2: 1024 positions 8x8x16, one
     // 8-wave workgroup per CU (halo redundancy 1.76x instead of 2.1x: less staging work per output)
-    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
+    // 2-D, HB 1: 256 positions 1x16x16 for grids that 512-position tiles leave under-filled at the widest cout tile (AE 512 / 384 channels
+    // @128x128: 128 / 96 workgroups on 256 CUs); 8 waves x 2 position tiles
+    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : (HB == 1 ? 16 : 32), TW = 16;
     // NT <= 2: 4 waves x 8 position-tiles (128 pos x 32*NT couts per wave, 2 workgroups per CU overlap staging and MFMA);
     // NT >= 3: 8 waves x 4 position-tiles (the accumulator would not fit otherwise)
     // 2-D, NT >= 3 (AE convs at 512^2 / 256^2: 9 taps per staged chunk, one workgroup per CU): 16 waves x 2 position tiles = 4 waves per SIMD
@@ -502,7 +507,7 @@ __global__ __launch_bounds__((GG_HALO_W16(D3, NT, HB) ? 1024 : (NT <= 2 && HB !=
 template <int D3, int NT, int UP, int HB = 0, int POST = 0>
 static int launch_halo(const ConvParams &p, hipStream_t stream)
 {
-    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : 32, TW = 16;
+    constexpr int TD = D3 ? (HB == 2 ? 8 : 4) : 1, TH = D3 ? (HB == 1 ? 4 : 8) : (HB == 1 ? 16 : 32), TW = 16;
     constexpr int HD = D3 ? (UP ? TD / 2 + 2 : TD + 2) : 1, HH = UP ? TH / 2 + 2 : TH + 2, HW = UP ? TW / 2 + 2 : TW + 2;
     constexpr bool G3 = (GG_HALO_G3 && D3 && (HB == 2 || (GG_HALO_G3_HB1 && HB == 1) || NT >= 3)) || (GG_HALO_G3_2D && !D3 && NT >= 3);
     constexpr int LDSB = ((HD * HH * HW * 64 + 1023) / 1024) * 1024 + (G3 ? 6 : 2) * NT * 2048;
@@ -639,5 +644,10 @@ int gg_conv_halo_try(const ConvParams &p, hipStream_t stream)
         return p.upsample ? launch_halo<1, 1, 1, 1>(p, stream) : launch_halo<1, 1, 0, 1>(p, stream);
     }
     if (d3) return p.upsample ? dispatch_nt<1, 1>(p, NT, stream) : dispatch_nt<1, 0>(p, NT, stream);
+    // 2-D grids that the 512-position tiles under-fill at the widest cout tile: 256-position boxes, twice the workgroups (path_hint 4: tests)
+    if (GG_HALO_2D_HB1 && NT >= 3 && (p.path_hint == 4 || ((p.path_hint == 0 || p.path_hint == 8) && blocks < 224))) {
+        if (NT == 4) return p.upsample ? launch_halo<0, 4, 1, 1>(p, stream) : launch_halo<0, 4, 0, 1>(p, stream);
+        return p.upsample ? launch_halo<0, 3, 1, 1>(p, stream) : launch_halo<0, 3, 0, 1>(p, stream);
+    }
     return p.upsample ? dispatch_nt<0, 1>(p, NT, stream) : dispatch_nt<0, 0>(p, NT, stream);
 }
