@@ -44,3 +44,53 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def _desc(lib_mod, N, D, H, W, cin, cout, k, stride=1, pad=1, upsample=False, out_f32=False, act=0):
+    import ctypes as C
+    d = lib_mod.ConvDesc()
+    up = 2 if upsample else 1
+    d.N, d.D, d.H, d.W = N, D, H, W
+    d.C1, d.C2 = (cin + 31) // 32 * 32, 0
+    d.Cout, d.Cout_pad = cout, (cout + 31) // 32 * 32
+    d.kd, d.kh, d.kw = k
+    d.stride, d.pad, d.upsample = stride, pad, 1 if upsample else 0
+    ext = lambda n, kk: (n * up if kk == 3 or upsample else n) if stride == 1 else (n + 2 * pad - 3) // 2 + 1
+    d.Do, d.Ho, d.Wo = (D * up if (k[0] == 3 and upsample) else D), ext(H, k[1]), ext(W, k[2])
+    d.out_dtype = 1 if out_f32 else 0
+    d.prologue_act = act
+    return d, C.byref(d)
+
+
+def test_dispatch_predicates_are_host_logic_and_follow_the_documented_rules():
+    """gg_conv_runs_halo_tile / gg_conv_fuses_prologue / gg_conv_fuses_posterior read no pointers and launch nothing: they are the
+    host-side dispatch rules (gg_conv_halo.hip) and can be pinned without a GPU."""
+    import __graft_entry__ as ge
+    from jointimagegeneration_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    lib = _lib.load()
+    GG_F32 = 1
+    assert _lib.ConvDesc().out_dtype == 0                       # GG_BF16 == 0 (guidegen_hip.h)
+    # CCDM 128^3: 64 -> 64 3x3x3 runs on the halo-tile kernel and keeps its GroupNorm*SiLU fused (one cout group)
+    d, ref = _desc(_lib, 1, 128, 128, 128, 64, 64, (3, 3, 3))
+    assert lib.gg_conv_runs_halo_tile(ref) == 1 and lib.gg_conv_fuses_prologue(ref) == 1 and lib.gg_conv_fuses_posterior(ref) == 0
+    # ... its head conv (K = 14 classes, fp32 logits) can take the reverse step as its epilogue; at 32^3 (other kernels) it cannot
+    d, ref = _desc(_lib, 1, 128, 128, 128, 64, 14, (3, 3, 3), out_f32=True)
+    assert d.out_dtype == GG_F32 and lib.gg_conv_fuses_posterior(ref) == 1
+    d, ref = _desc(_lib, 1, 32, 32, 32, 64, 14, (3, 3, 3), out_f32=True)
+    assert lib.gg_conv_fuses_posterior(ref) == 0
+    d, ref = _desc(_lib, 1, 128, 128, 128, 64, 20, (3, 3, 3), out_f32=True)          # more classes than one 16-cout tile
+    assert lib.gg_conv_fuses_posterior(ref) == 0
+    # autoencoder: 128 -> 128 @512^2 (one cout group of the 128-cout tile) fused; 512 -> 512 @128^2 (four groups re-stage a box) separate
+    d, ref = _desc(_lib, 1, 1, 512, 512, 128, 128, (1, 3, 3))
+    assert lib.gg_conv_runs_halo_tile(ref) == 1 and lib.gg_conv_fuses_prologue(ref) == 1
+    d, ref = _desc(_lib, 1, 1, 128, 128, 512, 512, (1, 3, 3))
+    assert lib.gg_conv_runs_halo_tile(ref) == 1 and lib.gg_conv_fuses_prologue(ref) == 0
+    d.path_hint = 1                                                                  # tests: "can it" rather than "should it"
+    assert lib.gg_conv_fuses_prologue(ref) == 1
+    # a 1x1 conv and a stride-2 conv never run on the halo-tile kernel
+    d, ref = _desc(_lib, 1, 128, 128, 128, 128, 64, (1, 1, 1), pad=0)
+    assert lib.gg_conv_runs_halo_tile(ref) == 0
+    d, ref = _desc(_lib, 1, 128, 128, 128, 64, 64, (3, 3, 3), stride=2)
+    assert lib.gg_conv_runs_halo_tile(ref) == 0
