@@ -98,6 +98,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is mandatory (there is no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or jointimagegeneration_amd/csrc/build.sh")
+    # torch FIRST: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so); loaded before this library, the dynamic loader binds
+    # libguidegen_hip.so's `libamdhip64.so.7` to that same copy.  The other order leaves TWO HIP runtimes in the process, and launches
+    # through the second one fail with "no ROCm-capable device is detected" on tensors the first one owns.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)
