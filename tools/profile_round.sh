@@ -19,14 +19,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 tools/perf_probe.py ccdm128 > /dev/null 2>&1
 python3 tools/pmc_parse.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_conv3d.json
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq_ccdm -- python3 tools/perf_probe.py ccdm128 > /dev/null 2>&1
-{ echo "## conv_halo_kernel<1, 2, 0, 2, 0> in python3 tools/perf_probe.py ccdm128"; python3 tools/pmc_sq.py "conv_halo_kernel<1, 2, 0, 2" $OUT/pmc_sq_ccdm; } > $OUT/pmc_sq_summary.txt
+{ for k in "conv_halo_kernel<1, 2, 0, 2, 0" "conv_halo_kernel<1, 4, 0, 0, 0" "conv_halo_kernel<1, 4, 1, 0, 0" "conv_halo_kernel<1, 1, 0, 1, 0"; do echo "## $k> in python3 tools/perf_probe.py ccdm128"; python3 tools/pmc_sq.py "$k" $OUT/pmc_sq_ccdm; done; } > $OUT/pmc_sq_summary.txt
 echo "ccdm passes done"
 # 4. AE decode + cond-encode @512^2: kernel stats, FETCH / WRITE / SQ for the 2-D halo conv and the single-head attention
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ae -o ae -- python3 tools/perf_probe.py ae > $OUT/ae_probe.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_ae -- python3 tools/perf_probe.py ae > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_ae -- python3 tools/perf_probe.py ae > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_sq_ae -- python3 tools/perf_probe.py ae > /dev/null 2>&1
-for k in "conv_halo_kernel<0, 4, 0" "conv_halo_kernel<0, 3, 0" "conv_halo_kernel<0, 4, 1" "attn_kernel<512" "attn_kernel<384" "conv_box2d_kernel<16, 8, 2"; do
+for k in "conv_halo_kernel<0, 4, 0, 0" "conv_halo_kernel<0, 4, 0, 1" "conv_halo_kernel<0, 3, 0, 0" "conv_halo_kernel<0, 3, 0, 1" "conv_halo_kernel<0, 4, 1, 0" "conv_halo_kernel<0, 4, 1, 1" "attn_kernel<512" "attn_kernel<384" "conv_box2d_kernel<16, 8, 2"; do
   { echo "## $k (AE decode + cond-encode @512^2, python3 tools/perf_probe.py ae; FETCH_SIZE raw KiB: x2 on gfx950 for wide reads)"; python3 tools/pmc_sq.py "$k" $OUT/pmc_sq_ae $OUT/pmc_fetch_ae $OUT/pmc_write_ae; } >> $OUT/pmc_ae_summary.txt
 done
 echo "ae passes done"
