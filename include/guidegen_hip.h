@@ -161,7 +161,8 @@ int64_t gg_conv_workspace_bytes(const gg_conv_desc *desc);
  * prologue-free conv is the faster form.  Halo-tile shapes CAN always fuse it (path_hint != 0 answers that); with path_hint 0 the answer
  * follows the measured rule in gg_conv_halo.hip (separate where a box is re-staged by several cout groups).  Box-kernel shapes: where the box is staged by at most two cout tiles.  Pointers are not read. */
 int gg_conv_fuses_prologue(const gg_conv_desc *desc);
-/* 1 if gg_conv_forward(desc) can run the CCDM reverse step as this (head) conv's epilogue (gg_conv_desc.post_xt). Pointers are not read. */
+/* 1 if gg_conv_forward(desc) can run the CCDM reverse step as this (head) conv's epilogue (gg_conv_desc.post_xt).  Pointers are not
+ * dereferenced; residual, gn_acc, ddim_x and the skip projection must be unset (they have no meaning on a head conv with this epilogue). */
 int gg_conv_fuses_posterior(const gg_conv_desc *desc);
 /* 1 if gg_conv_forward(desc) runs this shape on the halo-tile kernel (3x3(x3), stride 1, filled grid). Pointers are not read. */
 int gg_conv_runs_halo_tile(const gg_conv_desc *desc);
