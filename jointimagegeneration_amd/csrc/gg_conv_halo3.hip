@@ -36,7 +36,7 @@ constexpr int H3_XB = 69632;                                // one team's box, r
 constexpr int H3_WOFF = 2 * H3_XB;                          // weight slots behind the two boxes
 constexpr int H3_WSLOT = 3 * 4096;                          // one (kd, kh) line: 3 taps x (64 couts x 64 B)
 constexpr int H3_LDS = H3_WOFF + 2 * H3_WSLOT;              // 163 840 B = all of the CU's LDS
-constexpr int H3_SCRATCH = 65536;                           // statistics scratch inside the team's box (rows >= 1024: written last by the staging)
+[[maybe_unused]] constexpr int H3_SCRATCH = 65536;                           // statistics scratch inside the team's box (rows >= 1024: written last by the staging)
 
 // workgroup barrier as inline assembly: a compiler-level memory barrier too, and no implicit s_waitcnt (the staging team keeps its
 // global loads in flight across the line barriers)
@@ -56,7 +56,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_team_kernel(const ConvParam
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = wave >> 2, w = wave & 3;               // wave-uniform: every branch on them is a scalar branch
-    char *xs = smem + team * H3_XB;
     const unsigned lds0 = h3_lds_addr(smem);
 
     // W-line swizzle of the box image (gg_conv_halo.hip): chunk ^ f(hw), f = 2 for hw in {4,5,10..15}
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo3_team_kernel(const ConvParam
         const int coff = (second ? jc - p.nchunk1 : jc) * 32;
         const int id0 = it.d0 - 1, ih0 = it.h0 - 1, iw0 = it.w0 - 1;
         const bf16_t *srcn = src + (long long)it.n * p.D * p.H * p.W * Cs + coff;
-        float *ssb = reinterpret_cast<float *>(xs + H3_NROWS * 64);              // [scale 32 | shift 32] in the 512 spare bytes behind the box rows
+        // ([scale 32 | shift 32] of the chunk are parked in the 512 spare bytes behind the box rows: smem + team * H3_XB + H3_NROWS * 64)
         // box row of piece k is row0 + 64 k: (hd, hh, hw) stepped with carries (64 = 3 * 18 + 10)
         int chd = row0 / (H3_HH * H3_HW), chh, chw;
         {
